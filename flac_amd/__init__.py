@@ -1,0 +1,301 @@
+"""flac_amd — Python binding (ctypes) of libflacgpu, the MI355X FLAC frame engine.
+
+The product is the shared library (flac_amd/lib/libflacgpu.so, C ABI in
+include/flacgpu.h).  This module only marshals arguments: every call goes
+through the C ABI, and importing the module fails loudly when the library has
+not been built (run `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C flac_amd/csrc`).  There is no CPU fallback for the frame path.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflacgpu.so")
+
+OK = 0
+FRAME_OK, FRAME_BAD_CRC16, FRAME_BAD_SUBFRAME, FRAME_TRUNCATED, FRAME_LENGTH, FRAME_RANGE, FRAME_UNSUPPORTED, \
+    FRAME_SKIPPED = range(8)
+FLAG_TIMING = 1
+MAX_BLOCKS = 128
+
+# MetadataBlockType values as the reference numbers them (flacmeta.go:28-37).
+BLOCK_NAMES = {1: "STREAMINFO", 2: "PADDING", 3: "APPLICATION", 4: "SEEKTABLE", 5: "VORBIS_COMMENT",
+               6: "CUESHEET", 7: "PICTURE"}
+
+
+class StreamInfo(ctypes.Structure):
+    """StreaminfoBlock, flacmeta.go:263-273."""
+    _fields_ = [
+        ("min_blocksize", ctypes.c_uint16),
+        ("max_blocksize", ctypes.c_uint16),
+        ("min_framesize", ctypes.c_uint32),
+        ("max_framesize", ctypes.c_uint32),
+        ("sample_rate", ctypes.c_uint32),
+        ("channels", ctypes.c_uint8),
+        ("bits_per_sample", ctypes.c_uint8),
+        ("total_samples", ctypes.c_uint64),
+        ("md5", ctypes.c_uint8 * 16),
+    ]
+
+    @property
+    def md5_signature(self) -> str:
+        return bytes(self.md5).hex()
+
+    @property
+    def bytes_per_sample(self) -> int:
+        return (self.bits_per_sample + 7) // 8
+
+    @property
+    def pcm_bytes(self) -> int:
+        return int(self.total_samples) * self.channels * self.bytes_per_sample
+
+
+class SeekPoint(ctypes.Structure):
+    """SeekpointBlock, flacmeta.go:256-260."""
+    _fields_ = [("sample_number", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("frame_samples", ctypes.c_uint16)]
+
+
+class Block(ctypes.Structure):
+    """MetadataBlockHeader, flacmeta.go:235-240, plus the payload position."""
+    _fields_ = [("type", ctypes.c_uint32), ("length", ctypes.c_uint32), ("last", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("payload_offset", ctypes.c_uint64)]
+
+
+class Metadata(ctypes.Structure):
+    _fields_ = [("streaminfo", StreamInfo), ("has_streaminfo", ctypes.c_uint32), ("n_blocks", ctypes.c_uint32),
+                ("blocks", Block * MAX_BLOCKS), ("first_frame_offset", ctypes.c_uint64)]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("flags", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
+class Stream(ctypes.Structure):
+    _fields_ = [("in_offset", ctypes.c_uint64), ("in_length", ctypes.c_uint64), ("out_offset", ctypes.c_uint64),
+                ("out_capacity", ctypes.c_uint64), ("info", StreamInfo)]
+
+
+class StreamResult(ctypes.Structure):
+    _fields_ = [("sync_candidates", ctypes.c_uint64), ("header_candidates", ctypes.c_uint64),
+                ("frames", ctypes.c_uint64), ("frames_ok", ctypes.c_uint64), ("samples", ctypes.c_uint64),
+                ("pcm_bytes", ctypes.c_uint64)]
+
+
+class Frame(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_uint64), ("first_sample", ctypes.c_uint64), ("number", ctypes.c_uint64),
+                ("length", ctypes.c_uint32), ("blocksize", ctypes.c_uint32), ("stream", ctypes.c_uint32),
+                ("status", ctypes.c_int32), ("variable", ctypes.c_uint8), ("ch_assign", ctypes.c_uint8),
+                ("bps", ctypes.c_uint8), ("header_len", ctypes.c_uint8), ("reserved", ctypes.c_uint32)]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("scan_ms", ctypes.c_float), ("compact_ms", ctypes.c_float), ("crc16_ms", ctypes.c_float),
+                ("resolve_ms", ctypes.c_float), ("skim_ms", ctypes.c_float), ("decode_ms", ctypes.c_float),
+                ("results_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("candidates", ctypes.c_uint64),
+                ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# Every symbol include/flacgpu.h declares.
+EXPORTS = [
+    "flacgpu_parse_block_header", "flacgpu_parse_streaminfo", "flacgpu_parse_seektable", "flacgpu_parse_metadata",
+    "flacgpu_status_string", "flacgpu_create", "flacgpu_destroy", "flacgpu_last_error", "flacgpu_scan_frames",
+    "flacgpu_decode_batch_device", "flacgpu_decode_batch", "flacgpu_get_timing",
+]
+
+_lib = None
+
+
+class FlacError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = lib().flacgpu_status_string(status).decode()
+        super().__init__(f"flacgpu status {status}: {msg}" + (f" ({detail})" if detail else ""))
+
+
+def lib():
+    """Loads libflacgpu.so; raises if it is missing (there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `make -C flac_amd/csrc` (needs hipcc)")
+        # PyTorch wheels bundle their own HIP runtime (soname libamdhip64.so.7, loaded as
+        # "libamdhip64.so").  Two HIP runtimes in one process cannot both own the GPU, so when
+        # torch is installed it is imported first and libflacgpu binds to the runtime torch loaded.
+        if "torch" not in sys.modules and not os.environ.get("FLAC_AMD_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u64, u32, sz = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_size_t
+        L.flacgpu_parse_block_header.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(Block)]
+        L.flacgpu_parse_streaminfo.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(StreamInfo)]
+        L.flacgpu_parse_seektable.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(SeekPoint), sz, ctypes.POINTER(sz)]
+        L.flacgpu_parse_metadata.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(Metadata)]
+        L.flacgpu_status_string.restype = ctypes.c_char_p
+        L.flacgpu_status_string.argtypes = [ctypes.c_int]
+        L.flacgpu_create.argtypes = [ctypes.POINTER(Options), ctypes.POINTER(vp)]
+        L.flacgpu_destroy.argtypes = [vp]
+        L.flacgpu_destroy.restype = None
+        L.flacgpu_last_error.restype = ctypes.c_char_p
+        L.flacgpu_last_error.argtypes = [vp]
+        L.flacgpu_scan_frames.argtypes = [vp, vp, u64, ctypes.POINTER(Stream), u32, ctypes.POINTER(Frame), u64,
+                                          ctypes.POINTER(u64), ctypes.POINTER(StreamResult), vp]
+        L.flacgpu_decode_batch_device.argtypes = [vp, vp, u64, vp, u64, ctypes.POINTER(Stream), u32,
+                                                  ctypes.POINTER(StreamResult), vp]
+        L.flacgpu_decode_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(StreamInfo),
+                                           u32, ctypes.POINTER(vp), ctypes.POINTER(u64),
+                                           ctypes.POINTER(StreamResult)]
+        L.flacgpu_get_timing.argtypes = [vp, ctypes.POINTER(Timing)]
+        _lib = L
+    return _lib
+
+
+# ------------------------------------------------------------------ metadata
+
+def parse_block_header(b: bytes) -> Block:
+    """MarshalMetadataBlockHeader, flacmeta.go:519-551."""
+    out = Block()
+    rc = lib().flacgpu_parse_block_header(bytes(b), len(b), ctypes.byref(out))
+    if rc:
+        raise FlacError(rc)
+    return out
+
+
+def parse_streaminfo(b: bytes) -> StreamInfo:
+    """MarshalStreaminfoBlock, flacmeta.go:644-717."""
+    out = StreamInfo()
+    rc = lib().flacgpu_parse_streaminfo(bytes(b), len(b), ctypes.byref(out))
+    if rc:
+        raise FlacError(rc)
+    return out
+
+
+def parse_seektable(b: bytes):
+    """MarshalSeekpointBlock, flacmeta.go:612-641."""
+    n = ctypes.c_size_t()
+    rc = lib().flacgpu_parse_seektable(bytes(b), len(b), None, 0, ctypes.byref(n))
+    if rc:
+        raise FlacError(rc)
+    pts = (SeekPoint * max(1, n.value))()
+    rc = lib().flacgpu_parse_seektable(bytes(b), len(b), pts, n.value, ctypes.byref(n))
+    if rc:
+        raise FlacError(rc)
+    return [pts[i] for i in range(n.value)]
+
+
+def parse_metadata(buf: bytes) -> Metadata:
+    """(*Metadata).Read, flacmeta.go:749-850: returns the block table, STREAMINFO
+    and first_frame_offset (the reader position Read leaves behind)."""
+    out = Metadata()
+    rc = lib().flacgpu_parse_metadata(bytes(buf), len(buf), ctypes.byref(out))
+    if rc:
+        raise FlacError(rc)
+    return out
+
+
+# -------------------------------------------------------------- frame engine
+
+def _ptr(t):
+    """Device pointer of a torch tensor or a raw int."""
+    return t if isinstance(t, int) else t.data_ptr()
+
+
+class Decoder:
+    """One handle = one GPU's workspace (flacgpu_create / flacgpu_destroy)."""
+
+    def __init__(self, device=0, timing=False):
+        self._h = ctypes.c_void_p()
+        o = Options(ctypes.sizeof(Options), int(device), FLAG_TIMING if timing else 0, 0)
+        rc = lib().flacgpu_create(ctypes.byref(o), ctypes.byref(self._h))
+        if rc:
+            raise FlacError(rc, "flacgpu_create")
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib().flacgpu_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise FlacError(rc, lib().flacgpu_last_error(self._h).decode())
+
+    @staticmethod
+    def make_streams(entries):
+        """entries: iterable of (in_offset, in_length, out_offset, out_capacity, StreamInfo)."""
+        entries = list(entries)
+        arr = (Stream * len(entries))()
+        for i, (io, il, oo, oc, si) in enumerate(entries):
+            arr[i].in_offset, arr[i].in_length, arr[i].out_offset, arr[i].out_capacity = io, il, oo, oc
+            ctypes.memmove(ctypes.byref(arr[i].info), ctypes.byref(si), ctypes.sizeof(StreamInfo))
+        return arr
+
+    def scan_frames(self, d_in, in_bytes, streams, hip_stream=0):
+        n = len(streams)
+        res = (StreamResult * n)()
+        nf = ctypes.c_uint64()
+        rc = lib().flacgpu_scan_frames(self._h, _ptr(d_in), in_bytes, streams, n, None, 0, ctypes.byref(nf), res,
+                                       hip_stream or None)
+        self._check(rc)
+        frames = (Frame * max(1, nf.value))()
+        rc = lib().flacgpu_scan_frames(self._h, _ptr(d_in), in_bytes, streams, n, frames, nf.value,
+                                       ctypes.byref(nf), res, hip_stream or None)
+        self._check(rc)
+        return [frames[i] for i in range(nf.value)], list(res)
+
+    def decode_batch_device(self, d_in, in_bytes, d_out, out_bytes, streams, hip_stream=0, results=None):
+        n = len(streams)
+        res = results if results is not None else (StreamResult * n)()
+        rc = lib().flacgpu_decode_batch_device(self._h, _ptr(d_in), in_bytes, _ptr(d_out), out_bytes, streams, n,
+                                               res, hip_stream or None)
+        self._check(rc)
+        return res
+
+    def decode_batch(self, audio_list, infos):
+        """Host buffers in, host PCM out (copies over PCIe).  audio_list: per stream the bytes from frame 0."""
+        n = len(audio_list)
+        arrs = [np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8)) for a in audio_list]
+        outs = [np.zeros(si.pcm_bytes, dtype=np.uint8) for si in infos]
+        bufs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
+        sis = (StreamInfo * n)()
+        for i, si in enumerate(infos):
+            ctypes.memmove(ctypes.byref(sis[i]), ctypes.byref(si), ctypes.sizeof(StreamInfo))
+        optr = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (ctypes.c_uint64 * n)(*[o.size for o in outs])
+        res = (StreamResult * n)()
+        rc = lib().flacgpu_decode_batch(self._h, bufs, lens, sis, n, optr, caps, res)
+        self._check(rc)
+        return outs, list(res)
+
+    def timing(self) -> Timing:
+        t = Timing()
+        self._check(lib().flacgpu_get_timing(self._h, ctypes.byref(t)))
+        return t
+
+
+def decode_file(path_or_bytes, decoder: Decoder = None):
+    """Convenience: whole .flac file -> (pcm bytes as np.uint8, StreamInfo, StreamResult)."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview, np.ndarray)) \
+        else open(path_or_bytes, "rb").read()
+    data = bytes(data)
+    md = parse_metadata(data)
+    if not md.has_streaminfo:
+        raise FlacError(6, "no STREAMINFO block")
+    dec = decoder or Decoder()
+    outs, res = dec.decode_batch([data[md.first_frame_offset:]], [md.streaminfo])
+    return outs[0], md.streaminfo, res[0]

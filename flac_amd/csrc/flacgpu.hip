@@ -1,0 +1,419 @@
+// flacgpu.hip — host driver of libflacgpu: workspace management, kernel
+// sequencing and the C ABI declared in include/flacgpu.h.
+//
+// A decode call runs, on one HIP stream:
+//   scan mask -> tile prefix -> compact -> stream ranges -> CRC-16 spans ->
+//   resolve -> (per run of streams with equal channels / sample bytes)
+//   skim -> decode -> per-stream results.
+// Two small device-to-host reads happen in between: the candidate count (to
+// size the candidate arrays) and the per-stream candidate ranges (to size the
+// skim / decode grids).
+#include "../../include/flacgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+#include "frame_scan.hpp"
+#include "subframe.hpp"
+
+using namespace flacgpu;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+enum { EV_START, EV_SCAN, EV_COMPACT, EV_CRC, EV_RESOLVE, EV_SKIM, EV_DECODE, EV_RESULTS, EV_COUNT };
+
+}  // namespace
+
+struct flacgpu_handle {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    DevBuf streams, results, mask, tile_count, tile_base, counter;
+    DevBuf goff, num, info, stream, len, status, segcrc, seglen, subpos;
+    uint32_t cand_cap = 0;
+    hipEvent_t ev[EV_COUNT] = {};
+    flacgpu_timing timing = {};
+    std::vector<StreamDev> h_streams;
+    // state of the last scan, used by flacgpu_scan_frames
+    uint32_t n_cand = 0;
+};
+
+namespace {
+
+int fail(flacgpu_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, e_ == hipErrorOutOfMemory ? FLACGPU_ERR_NOMEM : FLACGPU_ERR_DEVICE, \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+int reserve(flacgpu_handle *h, DevBuf &b, size_t bytes)
+{
+    if (b.bytes >= bytes) return FLACGPU_OK;
+    if (b.p) { HIP_TRY(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return FLACGPU_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+}
+
+CandArrays cand_arrays(flacgpu_handle *h)
+{
+    CandArrays c;
+    c.goff = (uint64_t *)h->goff.p; c.num = (uint64_t *)h->num.p; c.info = (uint32_t *)h->info.p;
+    c.stream = (uint32_t *)h->stream.p; c.len = (uint32_t *)h->len.p; c.status = (int32_t *)h->status.p;
+    c.segcrc = (uint16_t *)h->segcrc.p; c.seglen = (uint32_t *)h->seglen.p; c.subpos = (uint32_t *)h->subpos.p;
+    return c;
+}
+
+int reserve_candidates(flacgpu_handle *h, uint32_t n)
+{
+    if (n <= h->cand_cap) return FLACGPU_OK;
+    const size_t cap = (size_t)n + n / 8 + 64;
+    int rc;
+    if ((rc = reserve(h, h->goff, cap * 8))) return rc;
+    if ((rc = reserve(h, h->num, cap * 8))) return rc;
+    if ((rc = reserve(h, h->info, cap * 4))) return rc;
+    if ((rc = reserve(h, h->stream, cap * 4))) return rc;
+    if ((rc = reserve(h, h->len, cap * 4))) return rc;
+    if ((rc = reserve(h, h->status, cap * 4))) return rc;
+    if ((rc = reserve(h, h->segcrc, cap * 2))) return rc;
+    if ((rc = reserve(h, h->seglen, cap * 4))) return rc;
+    if ((rc = reserve(h, h->subpos, cap * 8 * 4))) return rc;
+    h->cand_cap = (uint32_t)cap;
+    return FLACGPU_OK;
+}
+
+void mark(flacgpu_handle *h, int which, hipStream_t s)
+{
+    if (h->flags & FLACGPU_FLAG_TIMING) (void)hipEventRecord(h->ev[which], s);
+}
+
+// Validates the batch description and builds the device stream table.
+int build_streams(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes, const flacgpu_stream *streams, uint32_t n,
+                  bool need_out)
+{
+    h->h_streams.resize(n);
+    uint64_t prev_end = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const flacgpu_stream &s = streams[i];
+        if (s.in_offset < prev_end) return fail(h, FLACGPU_ERR_ARG, "streams must be in ascending, non-overlapping in_offset order");
+        if (s.in_offset > in_bytes || s.in_length > in_bytes - s.in_offset) return fail(h, FLACGPU_ERR_ARG, "stream exceeds the input buffer");
+        if (s.in_length >= (1ull << 31)) return fail(h, FLACGPU_ERR_UNSUPPORTED, "stream of 2 GiB or more");
+        if (need_out && (s.out_offset > out_bytes || s.out_capacity > out_bytes - s.out_offset))
+            return fail(h, FLACGPU_ERR_ARG, "stream exceeds the output buffer");
+        if (s.info.channels < 1 || s.info.channels > 8 || s.info.bits_per_sample < 4 || s.info.bits_per_sample > 32 ||
+            s.info.max_blocksize < 16)
+            return fail(h, FLACGPU_ERR_STREAMINFO, "STREAMINFO out of bounds");
+        prev_end = s.in_offset + s.in_length;
+        StreamDev d;
+        std::memset(&d, 0, sizeof d);
+        d.in_off = s.in_offset; d.in_len = s.in_length; d.out_off = s.out_offset;
+        d.out_cap = need_out ? s.out_capacity : ~0ull;
+        d.total_samples = s.info.total_samples; d.max_bs = s.info.max_blocksize;
+        d.channels = s.info.channels; d.bps = s.info.bits_per_sample; d.bytes_ps = (uint8_t)((s.info.bits_per_sample + 7) / 8);
+        h->h_streams[i] = d;
+    }
+    return FLACGPU_OK;
+}
+
+// Frame discovery: leaves the candidate arrays, statuses and per-stream ranges on the device
+// and h->h_streams[].cand_begin/end on the host.
+int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t n, hipStream_t st)
+{
+    int rc;
+    const uint64_t n_tiles64 = (in_bytes + kScanTileBytes - 1) / kScanTileBytes;
+    if (n_tiles64 == 0 || n_tiles64 > 0x7FFFFFFFull) return fail(h, FLACGPU_ERR_ARG, "input size out of range");
+    const uint32_t n_tiles = (uint32_t)n_tiles64;
+    const uint64_t n_mask64 = (in_bytes + 63) / 64;
+    if ((rc = reserve(h, h->streams, (size_t)n * sizeof(StreamDev)))) return rc;
+    if ((rc = reserve(h, h->results, (size_t)n * sizeof(ResultDev)))) return rc;
+    if ((rc = reserve(h, h->mask, n_mask64 * 8))) return rc;
+    if ((rc = reserve(h, h->tile_count, (size_t)n_tiles * 4))) return rc;
+    if ((rc = reserve(h, h->tile_base, (size_t)n_tiles * 4))) return rc;
+    if ((rc = reserve(h, h->counter, 64))) return rc;
+
+    HIP_TRY(hipMemcpyAsync(h->streams.p, h->h_streams.data(), (size_t)n * sizeof(StreamDev), hipMemcpyHostToDevice, st));
+    // granules past the end of the input are never written by the scan: clear the last mask word
+    HIP_TRY(hipMemsetAsync((uint8_t *)h->mask.p + (n_mask64 - 1) * 8, 0, 8, st));
+    mark(h, EV_START, st);
+    k_scan_mask<<<n_tiles, 256, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (uint16_t *)h->mask.p,
+                                         (uint32_t *)h->tile_count.p);
+    mark(h, EV_SCAN, st);
+    k_tile_prefix<<<1, 1024, 0, st>>>((const uint32_t *)h->tile_count.p, (uint32_t *)h->tile_base.p, n_tiles,
+                                      (uint32_t *)h->counter.p);
+    uint32_t n_cand = 0;
+    HIP_TRY(hipMemcpyAsync(&n_cand, h->counter.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->n_cand = n_cand;
+    if ((rc = reserve_candidates(h, n_cand ? n_cand : 1))) return rc;
+    CandArrays c = cand_arrays(h);
+    if (n_cand) {
+        k_compact<<<n_tiles, 256, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (const uint64_t *)h->mask.p,
+                                           n_mask64, (const uint32_t *)h->tile_count.p, (const uint32_t *)h->tile_base.p,
+                                           h->cand_cap, c);
+    }
+    k_stream_ranges<<<(n + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, n, c.goff, n_cand);
+    mark(h, EV_COMPACT, st);
+    if (n_cand) {
+        k_crc16_spans<<<(n_cand + 3) / 4, 256, 0, st>>>(d_in, (const StreamDev *)h->streams.p, c, n_cand);
+    }
+    mark(h, EV_CRC, st);
+    if (n_cand) {
+        k_resolve_fast<<<(n_cand + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, c, n_cand);
+        k_resolve_slow<<<(n + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, n, c);
+    }
+    mark(h, EV_RESOLVE, st);
+    HIP_TRY(hipMemcpyAsync(h->h_streams.data(), h->streams.p, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    return FLACGPU_OK;
+}
+
+int fetch_results(flacgpu_handle *h, uint32_t n, flacgpu_stream_result *results, hipStream_t st)
+{
+    k_results<<<(n + 3) / 4, 256, 0, st>>>((const StreamDev *)h->streams.p, n, cand_arrays(h), (ResultDev *)h->results.p);
+    mark(h, EV_RESULTS, st);
+    std::vector<ResultDev> tmp(n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->results.p, (size_t)n * sizeof(ResultDev), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (results)
+        for (uint32_t i = 0; i < n; ++i) {
+            results[i].sync_candidates = 0;
+            results[i].header_candidates = tmp[i].header_candidates;
+            results[i].frames = tmp[i].frames;
+            results[i].frames_ok = tmp[i].frames_ok;
+            results[i].samples = tmp[i].samples;
+            results[i].pcm_bytes = tmp[i].pcm_bytes;
+        }
+    return FLACGPU_OK;
+}
+
+void collect_timing(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes)
+{
+    flacgpu_timing t;
+    std::memset(&t, 0, sizeof t);
+    t.candidates = h->n_cand; t.in_bytes = in_bytes; t.out_bytes = out_bytes;
+    if (h->flags & FLACGPU_FLAG_TIMING) {
+        auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, h->ev[a], h->ev[b]); return ms; };
+        t.scan_ms = el(EV_START, EV_SCAN);
+        t.compact_ms = el(EV_SCAN, EV_COMPACT);
+        t.crc16_ms = el(EV_COMPACT, EV_CRC);
+        t.resolve_ms = el(EV_CRC, EV_RESOLVE);
+        t.skim_ms = el(EV_RESOLVE, EV_SKIM);
+        t.decode_ms = el(EV_SKIM, EV_DECODE);
+        t.results_ms = el(EV_DECODE, EV_RESULTS);
+        t.total_ms = el(EV_START, EV_RESULTS);
+    }
+    h->timing = t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int flacgpu_create(const flacgpu_options *opts, flacgpu_handle **out)
+{
+    if (!out) return FLACGPU_ERR_ARG;
+    *out = nullptr;
+    flacgpu_handle *h = new flacgpu_handle();
+    if (opts && opts->struct_size >= sizeof(flacgpu_options)) { h->device = opts->device; h->flags = opts->flags; }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || h->device < 0 || h->device >= count) { delete h; return FLACGPU_ERR_DEVICE; }
+    if (hipSetDevice(h->device) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
+    for (int i = 0; i < EV_COUNT; ++i)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
+    *out = h;
+    return FLACGPU_OK;
+}
+
+void flacgpu_destroy(flacgpu_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    DevBuf *all[] = {&h->streams, &h->results, &h->mask, &h->tile_count, &h->tile_base, &h->counter, &h->goff, &h->num,
+                     &h->info, &h->stream, &h->len, &h->status, &h->segcrc, &h->seglen, &h->subpos};
+    for (DevBuf *b : all) release(*b);
+    for (int i = 0; i < EV_COUNT; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+const char *flacgpu_last_error(const flacgpu_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int flacgpu_get_timing(const flacgpu_handle *h, flacgpu_timing *out)
+{
+    if (!h || !out) return FLACGPU_ERR_ARG;
+    *out = h->timing;
+    return FLACGPU_OK;
+}
+
+int flacgpu_scan_frames(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, const flacgpu_stream *streams,
+                        uint32_t n_streams, flacgpu_frame *frames, uint64_t cap, uint64_t *n_frames,
+                        flacgpu_stream_result *results, void *hip_stream)
+{
+    if (!h || !d_in || !streams || !n_streams || !n_frames) return fail(h, FLACGPU_ERR_ARG, "null argument");
+    if ((uintptr_t)d_in & 15) return fail(h, FLACGPU_ERR_ARG, "d_in must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    int rc = build_streams(h, in_bytes, 0, streams, n_streams, false);
+    if (rc) return rc;
+    if ((rc = run_scan(h, (const uint8_t *)d_in, in_bytes, n_streams, st))) return rc;
+    mark(h, EV_SKIM, st);
+    mark(h, EV_DECODE, st);
+    if ((rc = fetch_results(h, n_streams, results, st))) return rc;
+    collect_timing(h, in_bytes, 0);
+
+    const uint32_t nc = h->n_cand;
+    std::vector<uint64_t> goff(nc), num(nc);
+    std::vector<uint32_t> info(nc), stream(nc), len(nc);
+    std::vector<int32_t> status(nc);
+    if (nc) {
+        HIP_TRY(hipMemcpy(goff.data(), h->goff.p, (size_t)nc * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(num.data(), h->num.p, (size_t)nc * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(info.data(), h->info.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(stream.data(), h->stream.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(len.data(), h->len.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(status.data(), h->status.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+    }
+    uint64_t nf = 0;
+    int ret = FLACGPU_OK;
+    for (uint32_t r = 0; r < nc; ++r) {
+        if (status[r] == kFrameSkipped) continue;
+        if (frames) {
+            if (nf < cap) {
+                const StreamDev &s = h->h_streams[stream[r]];
+                flacgpu_frame f;
+                std::memset(&f, 0, sizeof f);
+                f.offset = goff[r] - s.in_off;
+                f.number = num[r];
+                f.variable = (uint8_t)info_var(info[r]);
+                f.first_sample = f.variable ? num[r] : num[r] * (uint64_t)s.max_bs;
+                f.length = len[r];
+                f.blocksize = info_bs(info[r]);
+                f.stream = stream[r];
+                f.status = status[r];
+                f.ch_assign = (uint8_t)info_ca(info[r]);
+                f.bps = (uint8_t)info_bps(info[r]);
+                f.header_len = (uint8_t)info_hl(info[r]);
+                frames[nf] = f;
+            } else {
+                ret = FLACGPU_ERR_CAPACITY;
+            }
+        }
+        ++nf;
+    }
+    *n_frames = nf;
+    return ret;
+}
+
+int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, void *d_out, uint64_t out_bytes,
+                                const flacgpu_stream *streams, uint32_t n_streams, flacgpu_stream_result *results,
+                                void *hip_stream)
+{
+    if (!h || !d_in || !d_out || !streams || !n_streams) return fail(h, FLACGPU_ERR_ARG, "null argument");
+    if ((uintptr_t)d_in & 15) return fail(h, FLACGPU_ERR_ARG, "d_in must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    int rc = build_streams(h, in_bytes, out_bytes, streams, n_streams, true);
+    if (rc) return rc;
+    if ((rc = run_scan(h, (const uint8_t *)d_in, in_bytes, n_streams, st))) return rc;
+
+    // runs of consecutive streams with the same channel count and sample bytes share launches
+    struct Run { uint32_t r_begin, r_end, C, B; };
+    std::vector<Run> runs;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        const StreamDev &s = h->h_streams[i];
+        if (s.cand_end == s.cand_begin) continue;
+        if (!runs.empty() && runs.back().C == s.channels && runs.back().B == s.bytes_ps && runs.back().r_end == s.cand_begin)
+            runs.back().r_end = s.cand_end;
+        else
+            runs.push_back({s.cand_begin, s.cand_end, s.channels, s.bytes_ps});
+    }
+    CandArrays c = cand_arrays(h);
+    for (const Run &r : runs) {
+        const uint32_t nf = r.r_end - r.r_begin;
+        k_skim<<<(nf + 255) / 256, 256, 0, st>>>((const uint8_t *)d_in, c, r.r_begin, r.r_end, r.C);
+    }
+    mark(h, EV_SKIM, st);
+    for (const Run &r : runs) {
+        const uint32_t nf = r.r_end - r.r_begin;
+        const uint32_t F = 64 / r.C;
+        const uint32_t waves = (nf + F - 1) / F;
+        const uint32_t row_stride = kTile * r.C * r.B + 4;
+        const uint32_t wave_bytes = ((F * row_stride + 15) & ~15u) + F * 16;
+        DecodeParams p;
+        p.in = (const uint8_t *)d_in; p.out = (uint8_t *)d_out; p.streams = (const StreamDev *)h->streams.p; p.c = c;
+        p.r_begin = r.r_begin; p.r_end = r.r_end; p.C = r.C; p.B = r.B;
+        k_decode<<<(waves + 3) / 4, 256, 4 * wave_bytes, st>>>(p);
+    }
+    mark(h, EV_DECODE, st);
+    if ((rc = fetch_results(h, n_streams, results, st))) return rc;
+    collect_timing(h, in_bytes, out_bytes);
+    return FLACGPU_OK;
+}
+
+int flacgpu_decode_batch(flacgpu_handle *h, const uint8_t *const *bufs, const uint64_t *lens,
+                         const flacgpu_streaminfo *infos, uint32_t n_streams, uint8_t *const *out_pcm,
+                         const uint64_t *out_caps, flacgpu_stream_result *results)
+{
+    if (!h || !bufs || !lens || !infos || !out_pcm || !out_caps || !n_streams) return fail(h, FLACGPU_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<flacgpu_stream> streams(n_streams);
+    uint64_t in_total = 0, out_total = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        streams[i].in_offset = in_total; streams[i].in_length = lens[i];
+        streams[i].out_offset = out_total; streams[i].out_capacity = out_caps[i];
+        streams[i].info = infos[i];
+        in_total += (lens[i] + 63) & ~63ull;
+        out_total += (out_caps[i] + 63) & ~63ull;
+    }
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_in, in_total + 64));
+    hipError_t e = hipMalloc((void **)&d_out, out_total + 64);
+    if (e != hipSuccess) { (void)hipFree(d_in); return fail(h, FLACGPU_ERR_NOMEM, "hipMalloc(out)"); }
+    int rc = FLACGPU_OK;
+    hipStream_t st = h->own_stream;
+    for (uint32_t i = 0; i < n_streams && rc == FLACGPU_OK; ++i)
+        if (hipMemcpyAsync(d_in + streams[i].in_offset, bufs[i], lens[i], hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(h, FLACGPU_ERR_DEVICE, "hipMemcpyAsync(H2D)");
+    if (rc == FLACGPU_OK && hipMemsetAsync(d_out, 0, out_total + 64, st) != hipSuccess) rc = fail(h, FLACGPU_ERR_DEVICE, "hipMemsetAsync");
+    if (rc == FLACGPU_OK) rc = flacgpu_decode_batch_device(h, d_in, in_total, d_out, out_total, streams.data(), n_streams, results, st);
+    for (uint32_t i = 0; i < n_streams && rc == FLACGPU_OK; ++i)
+        if (out_caps[i] && hipMemcpyAsync(out_pcm[i], d_out + streams[i].out_offset, out_caps[i], hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = fail(h, FLACGPU_ERR_DEVICE, "hipMemcpyAsync(D2H)");
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FLACGPU_OK) rc = fail(h, FLACGPU_ERR_DEVICE, "hipStreamSynchronize");
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

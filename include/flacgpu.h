@@ -1,0 +1,233 @@
+/*
+ * flacgpu.h — C ABI of libflacgpu, the MI355X (gfx950) FLAC frame engine.
+ *
+ * The library takes over where the reference Go package stops: after
+ * (*Metadata).Read (flacmeta.go:749-850) has consumed the metadata blocks, the
+ * reader sits on byte 0 of audio frame 0 (flacmeta.go:845-849).  Everything from
+ * that byte to the end of the file is this library's input, together with the
+ * values Read produced: the StreaminfoBlock (flacmeta.go:263-273) and,
+ * optionally, the SeekpointBlocks (flacmeta.go:256-260).
+ *
+ * The reference has no FFI of its own; these are the entry points a cgo
+ * binding of `package flac` would declare (INTEGRATION.md shows the binding).
+ * Plain pointers and sizes only; every function returns an int status
+ * (0 = FLACGPU_OK) and never aborts or throws across the boundary — malformed
+ * input, which makes the reference panic (it indexes short slices without a
+ * length check, e.g. flacmeta.go:687,693,702), yields a status here.
+ *
+ * Threading: the metadata functions are pure.  A handle owns one GPU's
+ * workspace; calls on one handle must be serialised by the caller, distinct
+ * handles are independent (one handle per GPU, one host thread or process per
+ * handle).
+ */
+#ifndef FLACGPU_H
+#define FLACGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLACGPU_API_VERSION 1
+
+/* ----------------------------------------------------------------- status */
+enum {
+    FLACGPU_OK = 0,
+    FLACGPU_ERR_ARG = 1,         /* null pointer, bad size, unsorted streams            */
+    FLACGPU_ERR_SIGNATURE = 2,   /* first four bytes are not "fLaC"  (flacmeta.go:759)  */
+    FLACGPU_ERR_BLOCK_TYPE = 3,  /* invalid or unknown block type    (flacmeta.go:546)  */
+    FLACGPU_ERR_DUPLICATE = 4,   /* two blocks of a once-only kind   (flacmeta.go:783..)*/
+    FLACGPU_ERR_TRUNCATED = 5,   /* input ends inside a header or block (:766, :777)    */
+    FLACGPU_ERR_STREAMINFO = 6,  /* STREAMINFO bounds violated       (flacmeta.go:688..)*/
+    FLACGPU_ERR_SEEKTABLE = 7,   /* length not a multiple of 18      (flacmeta.go:823)  */
+    FLACGPU_ERR_CAPACITY = 8,    /* caller's output array too small                     */
+    FLACGPU_ERR_DEVICE = 9,      /* HIP runtime error; see flacgpu_last_error           */
+    FLACGPU_ERR_NOMEM = 10,
+    FLACGPU_ERR_UNSUPPORTED = 11
+};
+
+/* Per-frame status in flacgpu_frame.status. */
+enum {
+    FLACGPU_FRAME_OK = 0,
+    FLACGPU_FRAME_BAD_CRC16 = 1,    /* no span starting at this header has a zero CRC-16 */
+    FLACGPU_FRAME_BAD_SUBFRAME = 2, /* reserved subframe type / invalid field            */
+    FLACGPU_FRAME_TRUNCATED = 3,    /* bitstream runs past the end of the frame          */
+    FLACGPU_FRAME_LENGTH = 4,       /* decoded length differs from the resolved length   */
+    FLACGPU_FRAME_RANGE = 5,        /* samples fall outside total_samples / out_capacity */
+    FLACGPU_FRAME_UNSUPPORTED = 6,
+    FLACGPU_FRAME_SKIPPED = 7       /* header candidate inside another frame's span      */
+};
+
+/* -------------------------------------------------- metadata (CPU, pure) */
+
+/* MetadataBlockType as the reference numbers it: FlacSignature takes iota 0
+ * (flacmeta.go:28-37), so STREAMINFO = 1 ... PICTURE = 7, INVALID = 127; the
+ * wire code is this value minus one (HeaderType, flacmeta.go:142-162). */
+enum {
+    FLACGPU_BLOCK_STREAMINFO = 1,
+    FLACGPU_BLOCK_PADDING = 2,
+    FLACGPU_BLOCK_APPLICATION = 3,
+    FLACGPU_BLOCK_SEEKTABLE = 4,
+    FLACGPU_BLOCK_VORBIS_COMMENT = 5,
+    FLACGPU_BLOCK_CUESHEET = 6,
+    FLACGPU_BLOCK_PICTURE = 7,
+    FLACGPU_BLOCK_INVALID = 127
+};
+
+/* StreaminfoBlock, flacmeta.go:263-273 (MD5Signature as 16 raw bytes). */
+typedef struct flacgpu_streaminfo {
+    uint16_t min_blocksize;
+    uint16_t max_blocksize;
+    uint32_t min_framesize;
+    uint32_t max_framesize;
+    uint32_t sample_rate;
+    uint8_t  channels;
+    uint8_t  bits_per_sample;
+    uint64_t total_samples;
+    uint8_t  md5[16];
+} flacgpu_streaminfo;
+
+/* SeekpointBlock, flacmeta.go:256-260. */
+typedef struct flacgpu_seekpoint {
+    uint64_t sample_number;   /* 0xFFFFFFFFFFFFFFFF = placeholder */
+    uint64_t offset;          /* bytes from frame 0               */
+    uint16_t frame_samples;
+} flacgpu_seekpoint;
+
+/* MetadataBlockHeader, flacmeta.go:235-240, plus where its payload lies. */
+typedef struct flacgpu_block {
+    uint32_t type;            /* FLACGPU_BLOCK_*                  */
+    uint32_t length;          /* payload bytes                    */
+    uint32_t last;            /* 0 / 1                            */
+    uint32_t reserved;
+    uint64_t payload_offset;  /* from byte 0 of the file          */
+} flacgpu_block;
+
+#define FLACGPU_MAX_BLOCKS 128
+
+/* What Metadata.Read establishes that the frame engine needs. */
+typedef struct flacgpu_metadata {
+    flacgpu_streaminfo streaminfo;
+    uint32_t has_streaminfo;
+    uint32_t n_blocks;
+    flacgpu_block blocks[FLACGPU_MAX_BLOCKS];
+    uint64_t first_frame_offset;   /* reader position on return of Read, flacmeta.go:845-849 */
+} flacgpu_metadata;
+
+/* MarshalMetadataBlockHeader, flacmeta.go:519-551.  b: 4 bytes. */
+int flacgpu_parse_block_header(const uint8_t *b, size_t n, flacgpu_block *out);
+
+/* MarshalStreaminfoBlock, flacmeta.go:644-717.  b: the 34-byte payload. */
+int flacgpu_parse_streaminfo(const uint8_t *b, size_t n, flacgpu_streaminfo *out);
+
+/* MarshalSeekpointBlock, flacmeta.go:612-641 (with the length rule of :823). */
+int flacgpu_parse_seektable(const uint8_t *b, size_t n, flacgpu_seekpoint *out, size_t cap, size_t *count);
+
+/* (*Metadata).Read, flacmeta.go:749-850: marker, block loop, duplicate rules. */
+int flacgpu_parse_metadata(const uint8_t *buf, size_t len, flacgpu_metadata *out);
+
+const char *flacgpu_status_string(int status);
+
+/* ------------------------------------------------------ frame engine (GPU) */
+
+typedef struct flacgpu_handle flacgpu_handle;
+
+typedef struct flacgpu_options {
+    uint32_t struct_size;     /* sizeof(flacgpu_options)                          */
+    int32_t  device;          /* HIP device ordinal                               */
+    uint32_t flags;           /* FLACGPU_FLAG_*                                   */
+    uint32_t reserved;
+} flacgpu_options;
+
+#define FLACGPU_FLAG_TIMING 1u   /* record HIP events around every kernel stage */
+
+/* One stream of a batch.  All streams of a batch live in ONE device buffer
+ * (d_in), in ascending, non-overlapping in_offset order; their PCM goes to ONE
+ * device buffer (d_out). */
+typedef struct flacgpu_stream {
+    uint64_t in_offset;       /* bytes from d_in to byte 0 of frame 0             */
+    uint64_t in_length;       /* bytes of audio frames                            */
+    uint64_t out_offset;      /* bytes from d_out to this stream's first sample   */
+    uint64_t out_capacity;    /* bytes this stream may write                      */
+    flacgpu_streaminfo info;  /* from flacgpu_parse_metadata / Metadata.Read      */
+} flacgpu_stream;
+
+typedef struct flacgpu_stream_result {
+    uint64_t sync_candidates;   /* not filled by the GPU path (0)                 */
+    uint64_t header_candidates; /* headers passing validity + CRC-8               */
+    uint64_t frames;            /* resolved frames, any status                    */
+    uint64_t frames_ok;
+    uint64_t samples;           /* inter-channel samples in OK frames             */
+    uint64_t pcm_bytes;         /* end of the highest OK frame, bytes             */
+} flacgpu_stream_result;
+
+/* One resolved frame, as flacgpu_scan_frames reports it. */
+typedef struct flacgpu_frame {
+    uint64_t offset;          /* bytes from frame 0 of its stream                 */
+    uint64_t first_sample;    /* inter-channel sample index                       */
+    uint64_t number;          /* coded frame / sample number                      */
+    uint32_t length;          /* bytes, sync code through CRC-16                  */
+    uint32_t blocksize;
+    uint32_t stream;          /* index into the batch                             */
+    int32_t  status;          /* FLACGPU_FRAME_*                                  */
+    uint8_t  variable;        /* blocking-strategy bit                            */
+    uint8_t  ch_assign;       /* 0..10                                            */
+    uint8_t  bps;
+    uint8_t  header_len;      /* bytes including CRC-8                            */
+    uint32_t reserved;
+} flacgpu_frame;
+
+/* Device time of the last decode/scan call, milliseconds (FLACGPU_FLAG_TIMING). */
+typedef struct flacgpu_timing {
+    float scan_ms;       /* sync search + header validation + CRC-8 (candidate mask)   */
+    float compact_ms;    /* prefix sum + ordered candidate list                         */
+    float crc16_ms;      /* CRC-16 of every candidate span                              */
+    float resolve_ms;    /* span resolution + range checks                              */
+    float skim_ms;       /* subframe start positions                                    */
+    float decode_ms;     /* Rice + prediction + decorrelation + PCM packing             */
+    float results_ms;    /* per-stream reduction                                        */
+    float total_ms;      /* first kernel to last kernel                                 */
+    uint64_t candidates;
+    uint64_t in_bytes;
+    uint64_t out_bytes;
+} flacgpu_timing;
+
+int  flacgpu_create(const flacgpu_options *opts, flacgpu_handle **out);
+void flacgpu_destroy(flacgpu_handle *h);
+const char *flacgpu_last_error(const flacgpu_handle *h);
+
+/* Frame discovery only: fills `frames` (host array of `cap` entries) with the
+ * resolved frames of all streams in stream order, and *n_frames.  d_in is a
+ * device pointer.  hip_stream: a hipStream_t, or NULL for the handle's own. */
+int flacgpu_scan_frames(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
+                        const flacgpu_stream *streams, uint32_t n_streams,
+                        flacgpu_frame *frames, uint64_t cap, uint64_t *n_frames,
+                        flacgpu_stream_result *results, void *hip_stream);
+
+/* Decode a device-resident batch: frame scan, Rice/LPC reconstruction,
+ * decorrelation, and packing to interleaved signed little-endian samples of
+ * ceil(bps/8) bytes (the byte string the STREAMINFO MD5 is defined over),
+ * frame i of a stream written at first_sample * channels * bytes.  Frames
+ * whose status is not OK leave their part of d_out unspecified.  Returns when
+ * the work is complete. */
+int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
+                                void *d_out, uint64_t out_bytes,
+                                const flacgpu_stream *streams, uint32_t n_streams,
+                                flacgpu_stream_result *results, void *hip_stream);
+
+/* Host-buffer convenience: bufs[i] points at frame 0 of stream i (lens[i]
+ * bytes); PCM lands in out_pcm[i] (out_caps[i] bytes).  Copies in and out over
+ * PCIe around flacgpu_decode_batch_device. */
+int flacgpu_decode_batch(flacgpu_handle *h, const uint8_t *const *bufs, const uint64_t *lens,
+                         const flacgpu_streaminfo *infos, uint32_t n_streams,
+                         uint8_t *const *out_pcm, const uint64_t *out_caps,
+                         flacgpu_stream_result *results);
+
+int flacgpu_get_timing(const flacgpu_handle *h, flacgpu_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def testdata():
+    return os.path.join(ROOT, "testdata")
+
+
+@pytest.fixture(scope="session")
+def decoder():
+    import flac_amd
+    d = flac_amd.Decoder(0, timing=True)
+    yield d
+    d.close()
