@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — decode throughput of libflacgpu on the BASELINE workload.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on;
+configs[1] is the two tiny reference fixtures and is a parity test, not a bench
+line): FILES (default 10 000) FLAC files of 60 s, 44.1 kHz, 16-bit stereo,
+block size 4096, fixed + LPC (order <= 12) subframes, Rice partition order <= 6.
+UNIQUE (default 256) distinct files are synthesised and encoded on the host by
+synth/ (seeded PRNG; no dataset exists offline) and replicated on the device to
+FILES independent streams, each with its own input bytes and its own output
+region, all resident in HBM before the timed region starts.
+
+A step = one flacgpu_decode_batch_device call over the whole batch: frame scan
+(sync + CRC-8 + CRC-16), subframe skim, Rice/LPC decode, decorrelation and
+packing to interleaved s16le PCM.  With N ranks every rank decodes its own
+batch of FILES files (weak scaling, no collective on the data path).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--files", type=int, default=10000)
+    ap.add_argument("--unique", type=int, default=256)
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--cpu-files", type=int, default=64, help="files of the workload timed on the host CPU (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import flac_amd
+    import synth
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    rate, channels, bps, blocksize = 44100, 2, 16, 4096
+    nsamples = int(round(args.seconds * rate))
+    pcm_bytes_per_file = nsamples * channels * 2
+    unique = max(1, min(args.unique, args.files))
+
+    # ---- corpus: UNIQUE files synthesised + encoded on the host ------------------------------
+    threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+    enc_threads = max(1, threads // max(1, min(world, 8))) if world > 1 else threads
+    t0 = time.time()
+    opts = synth.options(blocksize, 12, max_partition_order=6)
+    files, ffs = synth.make_batch(rank * unique, unique, nsamples, channels, bps, rate, opts, nthreads=enc_threads)
+    infos, audios = [], []
+    for f, ff in zip(files, ffs):
+        md = flac_amd.parse_metadata(f[: ff + 64].tobytes())
+        assert md.first_frame_offset == ff and md.has_streaminfo
+        si = flac_amd.StreamInfo()
+        ctypes.memmove(ctypes.byref(si), ctypes.byref(md.streaminfo), ctypes.sizeof(si))
+        infos.append(si)
+        audios.append(f[ff:])
+    comp_unique = sum(a.size for a in audios)
+    if rank == 0:
+        log(f"corpus: {unique} unique files, {comp_unique / 1e6:.1f} MB FLAC for {unique * pcm_bytes_per_file / 1e6:.1f} MB PCM "
+            f"(ratio {comp_unique / (unique * pcm_bytes_per_file):.3f}) in {time.time() - t0:.1f} s on {enc_threads} threads")
+
+    # ---- device-resident batch ---------------------------------------------------------------
+    nfiles = args.files
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    per_file = (comp_unique / unique) * 1.15 + pcm_bytes_per_file + 64 * 1024
+    fit = int((free_b - 6e9) / per_file)
+    if fit < nfiles:
+        log(f"only {free_b / 1e9:.0f} GB free: batch reduced from {nfiles} to {fit} files")
+        nfiles = max(1, fit)
+    in_offs = np.zeros(nfiles, dtype=np.int64)
+    pos = 0
+    for i in range(nfiles):
+        in_offs[i] = pos
+        pos += (audios[i % unique].size + 255) // 256 * 256
+    in_bytes = pos
+    out_stride = (pcm_bytes_per_file + 255) // 256 * 256
+    out_bytes = out_stride * nfiles
+    d_in = torch.empty(in_bytes, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+    d_unique = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in audios]
+    for i in range(nfiles):
+        u = d_unique[i % unique]
+        d_in[in_offs[i]: in_offs[i] + u.numel()].copy_(u)
+    torch.cuda.synchronize(dev)
+    del d_unique
+    streams = flac_amd.Decoder.make_streams(
+        (int(in_offs[i]), audios[i % unique].size, i * out_stride, pcm_bytes_per_file, infos[i % unique])
+        for i in range(nfiles))
+    comp_total = sum(audios[i % unique].size for i in range(nfiles))
+    pcm_total = nfiles * pcm_bytes_per_file
+    values_total = nfiles * nsamples * channels
+    if rank == 0:
+        log(f"batch: {nfiles} files, {comp_total / 1e9:.2f} GB FLAC in HBM -> {pcm_total / 1e9:.2f} GB PCM")
+
+    dec = flac_amd.Decoder(local_rank, timing=True)
+    hip_stream = torch.cuda.current_stream(dev).cuda_stream
+    results = (flac_amd.StreamResult * nfiles)()
+
+    def step():
+        dec.decode_batch_device(d_in, in_bytes, d_out, out_bytes, streams, hip_stream=hip_stream, results=results)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for w in range(args.warmup):
+        step()
+        if rank == 0:
+            log(f"warmup {w}: {dec.timing().total_ms:.1f} ms device time")
+    # correctness of what is about to be timed: every frame decoded, PCM matches the STREAMINFO MD5
+    import hashlib
+    if args.warmup == 0:
+        step()
+    exp_frames = (nsamples + blocksize - 1) // blocksize
+    bad = [i for i in range(nfiles) if results[i].frames_ok != exp_frames or results[i].samples != nsamples]
+    assert not bad, f"{len(bad)} streams did not decode completely (first: {bad[:4]})"
+    for i in sorted({0, nfiles // 2, nfiles - 1}):
+        got = d_out[i * out_stride: i * out_stride + pcm_bytes_per_file].cpu().numpy()
+        assert hashlib.md5(got.tobytes()).hexdigest() == infos[i % unique].md5_signature, f"MD5 mismatch, stream {i}"
+
+    kernel_ms = {k: 0.0 for k in ("scan_ms", "compact_ms", "crc16_ms", "resolve_ms", "skim_ms", "decode_ms", "results_ms", "total_ms")}
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t = dec.timing()
+        for k in kernel_ms:
+            kernel_ms[k] += getattr(t, k)
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        vv = torch.tensor([float(values_total), float(pcm_total), float(comp_total)], dtype=torch.float64, device=dev)
+        dist.all_reduce(vv, op=dist.ReduceOp.SUM)
+        values_all, pcm_all, comp_all = [float(x) for x in vv.tolist()]
+    else:
+        values_all, pcm_all, comp_all = float(values_total), float(pcm_total), float(comp_total)
+    for k in kernel_ms:
+        kernel_ms[k] /= max(1, args.steps)
+
+    # ---- CPU baseline: the oracle (a scalar C port), timed on this host's cores on a sample ---
+    cpu = None
+    if rank == 0 and args.cpu_files > 0:
+        import oracle
+        ncpu = min(args.cpu_files, unique)
+        offs, lens, pos = [], [], 0
+        for i in range(ncpu):
+            offs.append(pos)
+            lens.append(audios[i].size)
+            pos += audios[i].size
+        blob = np.concatenate([audios[i] for i in range(ncpu)])
+        pcm = np.zeros(ncpu * pcm_bytes_per_file, dtype=np.uint8)
+        oinfos = []
+        for i in range(ncpu):
+            o = oracle.StreamInfo()
+            ctypes.memmove(ctypes.byref(o), ctypes.byref(infos[i]), ctypes.sizeof(o))
+            oinfos.append(o)
+        t0 = time.perf_counter()
+        _, st = oracle.decode_batch(blob, offs, lens, oinfos, pcm, [i * pcm_bytes_per_file for i in range(ncpu)],
+                                    [pcm_bytes_per_file] * ncpu, nthreads=threads)
+        cpu_s = time.perf_counter() - t0
+        assert all(s.frames_ok == exp_frames for s in st)
+        got = d_out[:pcm_bytes_per_file].cpu().numpy()
+        assert np.array_equal(got, pcm[:pcm_bytes_per_file]), "GPU PCM differs from the CPU oracle"
+        cpu = {"value": ncpu * nsamples * channels / cpu_s, "unit": "samples/s", "cores": threads, "kind": "port",
+               "sample": f"{ncpu} of the {unique} unique files ({ncpu * pcm_bytes_per_file / 1e6:.0f} MB PCM), "
+                         f"oracle/flac_oracle.c, {threads} threads, {cpu_s:.2f} s"}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        alg_bytes = comp_total + pcm_total            # per launch of the decode kernel (one rank)
+        dec_s = kernel_ms["decode_ms"] / 1e3
+        achieved = alg_bytes / dec_s / 1e9 if dec_s > 0 else 0.0
+        out = {
+            "metric": "decoded PCM samples/sec",
+            "value": values_all * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{nfiles} x {args.seconds:g} s 44.1 kHz 16-bit stereo FLAC, blocksize 4096, fixed+LPC(<=12), "
+                            f"{unique} unique files replicated in HBM (BASELINE configs[2])",
+                "files_per_gpu": nfiles, "unique_files": unique,
+                "compressed_GB_per_gpu": comp_total / 1e9, "pcm_GB_per_gpu": pcm_total / 1e9,
+            },
+            "pcm_MB_per_s": pcm_all * args.steps / elapsed / 1e6,
+            "algorithmic_GB_per_s": (pcm_all + comp_all) * args.steps / elapsed / 1e9,
+            "kernel_ms": kernel_ms,
+            "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms["decode_ms"]},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,8 @@ import os
 import numpy as np
 import pytest
 
-from util import flac_amd, gpu_batch, make_file, md5hex, oracle, oracle_decode, split_file, synth, to_oracle_si
+from cases import CASES, encode_case
+from util import flac_amd, gpu_batch, md5hex, oracle, oracle_decode, split_file, synth, to_oracle_si
 
 pytestmark = pytest.mark.gpu
 
@@ -58,51 +59,10 @@ def test_fixture_frame_tables(decoder, testdata):
                                                   o.status, o.ch_assign, o.bps, o.header_len, o.variable)
 
 
-CASES = [
-    dict(name="stereo16-lpc12", channels=2, bps=16, n=4096 * 5 + 1234, bs=4096),
-    dict(name="stereo16-fixed", channels=2, bps=16, n=20000, bs=4096, max_lpc_order=0),
-    dict(name="mono16", channels=1, bps=16, n=30000, bs=4096),
-    dict(name="8ch24-lpc32-po8", channels=8, bps=24, n=16384 * 2 + 100, bs=16384, rate=192000, max_lpc_order=32,
-         force_lpc_order=32, force_partition_order=8),
-    dict(name="stereo24", channels=2, bps=24, n=20000, bs=4608, rate=96000),
-    dict(name="verbatim", channels=2, bps=16, n=5000, bs=1152, force_verbatim=1),
-    dict(name="escape-all", channels=2, bps=16, n=6000, bs=1024, escape_mode=2),
-    dict(name="escape-some", channels=2, bps=16, n=6000, bs=1024, escape_mode=1),
-    dict(name="rice5", channels=2, bps=16, n=6000, bs=1024, rice_method=1),
-    dict(name="left-right", channels=2, bps=16, n=6000, bs=1024, stereo_mode=0),
-    dict(name="left-side", channels=2, bps=16, n=6000, bs=1024, stereo_mode=1),
-    dict(name="side-right", channels=2, bps=16, n=6000, bs=1024, stereo_mode=2),
-    dict(name="mid-side", channels=2, bps=16, n=6000, bs=1024, stereo_mode=3),
-    dict(name="fixed0", channels=2, bps=16, n=5000, bs=576, force_fixed_order=0),
-    dict(name="fixed1", channels=2, bps=16, n=5000, bs=576, force_fixed_order=1),
-    dict(name="fixed2", channels=2, bps=16, n=5000, bs=576, force_fixed_order=2),
-    dict(name="fixed3", channels=2, bps=16, n=5000, bs=576, force_fixed_order=3),
-    dict(name="fixed4", channels=2, bps=16, n=5000, bs=576, force_fixed_order=4),
-    dict(name="variable-bs", channels=2, bps=16, n=30000, bs=4096, variable_blocksize=1,
-         var_sizes=[1024, 4096, 576, 2000]),
-    dict(name="3ch12-bs1000", channels=3, bps=12, n=7777, bs=1000),
-    dict(name="mono8", channels=1, bps=8, n=5000, bs=256),
-    dict(name="5ch20", channels=5, bps=20, n=9000, bs=2048, rate=48000),
-    dict(name="stereo32", channels=2, bps=32, n=5000, bs=512, stereo_mode=0),
-    dict(name="lpc32-16bit", channels=2, bps=16, n=9000, bs=4096, max_lpc_order=32),
-    dict(name="mono24-odd", channels=1, bps=24, n=5001, bs=1001),
-    dict(name="tiny", channels=2, bps=16, n=17, bs=4096),
-]
-
-
-def _encode_case(i, c):
-    c = dict(c)
-    name = c.pop("name")
-    n, bs = c.pop("n"), c.pop("bs")
-    f, x = make_file(100 + i, n, c.pop("channels"), c.pop("bps"), c.pop("rate", 44100), bs,
-                     c.pop("max_lpc_order", 12), **c)
-    return name, f, x
-
-
 def test_synthetic_cases_one_batch(decoder):
     """Every subframe type / Rice mode / channel layout in ONE mixed batch, against
     the oracle and against the source PCM (lossless round trip + STREAMINFO MD5)."""
-    enc = [_encode_case(i, c) for i, c in enumerate(CASES)]
+    enc = [encode_case(i, c) for i, c in enumerate(CASES)]
     files = [f for _, f, _ in enc]
     pcms, res, infos = gpu_batch(decoder, files, out_fill=0xAA)
     for (name, f, x), p, r, si in zip(enc, pcms, res, infos):
