@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -39,7 +40,7 @@ struct flacgpu_handle {
     uint32_t flags = 0;
     hipStream_t own_stream = nullptr;
     std::string err;
-    DevBuf streams, results, mask, tile_count, tile_base, counter;
+    DevBuf streams, results, mask, tile_count, tile_base, counter, crc_tables;
     DevBuf goff, num, info, stream, len, status, segcrc, seglen, subpos;
     uint32_t cand_cap = 0;
     hipEvent_t ev[EV_COUNT] = {};
@@ -180,7 +181,9 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     k_stream_ranges<<<(n + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, n, c.goff, n_cand);
     mark(h, EV_COMPACT, st);
     if (n_cand) {
-        k_crc16_spans<<<(n_cand + 3) / 4, 256, 0, st>>>(d_in, (const StreamDev *)h->streams.p, c, n_cand);
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_cand + 3) / 4, 256 * 8);
+        k_crc16_spans<<<blocks, 256, 0, st>>>(d_in, (const StreamDev *)h->streams.p, c, n_cand,
+                                               (const uint16_t *)h->crc_tables.p);
     }
     mark(h, EV_CRC, st);
     if (n_cand) {
@@ -250,6 +253,10 @@ int flacgpu_create(const flacgpu_options *opts, flacgpu_handle **out)
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
+    if (hipMalloc(&h->crc_tables.p, kCrcTableEntries * 2) != hipSuccess) { flacgpu_destroy(h); return FLACGPU_ERR_NOMEM; }
+    h->crc_tables.bytes = kCrcTableEntries * 2;
+    k_crc16_build_tables<<<1, 256, 0, h->own_stream>>>((uint16_t *)h->crc_tables.p);
+    if (hipStreamSynchronize(h->own_stream) != hipSuccess) { flacgpu_destroy(h); return FLACGPU_ERR_DEVICE; }
     *out = h;
     return FLACGPU_OK;
 }
@@ -258,7 +265,7 @@ void flacgpu_destroy(flacgpu_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    DevBuf *all[] = {&h->streams, &h->results, &h->mask, &h->tile_count, &h->tile_base, &h->counter, &h->goff, &h->num,
+    DevBuf *all[] = {&h->streams, &h->results, &h->mask, &h->tile_count, &h->tile_base, &h->counter, &h->crc_tables, &h->goff, &h->num,
                      &h->info, &h->stream, &h->len, &h->status, &h->segcrc, &h->seglen, &h->subpos};
     for (DevBuf *b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -359,21 +366,32 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
             runs.push_back({s.cand_begin, s.cand_end, s.channels, s.bytes_ps});
     }
     CandArrays c = cand_arrays(h);
+    const uint64_t in_vecs = (in_bytes + 15) / 16;
     for (const Run &r : runs) {
         const uint32_t nf = r.r_end - r.r_begin;
-        k_skim<<<(nf + 255) / 256, 256, 0, st>>>((const uint8_t *)d_in, c, r.r_begin, r.r_end, r.C);
+        k_skim<<<(nf + 255) / 256, 256, 0, st>>>((const uint8_t *)d_in, in_vecs, c, r.r_begin, r.r_end, r.C);
     }
     mark(h, EV_SKIM, st);
     for (const Run &r : runs) {
         const uint32_t nf = r.r_end - r.r_begin;
         const uint32_t F = 64 / r.C;
         const uint32_t waves = (nf + F - 1) / F;
-        const uint32_t row_stride = kTile * r.C * r.B + 4;
-        const uint32_t wave_bytes = ((F * row_stride + 15) & ~15u) + F * 16;
+        const uint32_t blocks = (waves + 3) / 4;
         DecodeParams p;
-        p.in = (const uint8_t *)d_in; p.out = (uint8_t *)d_out; p.streams = (const StreamDev *)h->streams.p; p.c = c;
+        p.in = (const uint8_t *)d_in; p.in_vecs = in_vecs; p.out = (uint8_t *)d_out;
+        p.streams = (const StreamDev *)h->streams.p; p.c = c;
         p.r_begin = r.r_begin; p.r_end = r.r_end; p.C = r.C; p.B = r.B;
-        k_decode<<<(waves + 3) / 4, 256, 4 * wave_bytes, st>>>(p);
+        // every predictor-length class is launched over the same grid; a wave runs in exactly one
+#define FLACGPU_LAUNCH(MO, W, S) \
+        k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C, r.B), st>>>(p)
+        if (r.C == 2 && r.B == 2) {
+            FLACGPU_LAUNCH(4, false, true); FLACGPU_LAUNCH(12, false, true); FLACGPU_LAUNCH(32, false, true);
+            FLACGPU_LAUNCH(12, true, true); FLACGPU_LAUNCH(32, true, true);
+        } else {
+            FLACGPU_LAUNCH(4, false, false); FLACGPU_LAUNCH(12, false, false); FLACGPU_LAUNCH(32, false, false);
+            FLACGPU_LAUNCH(12, true, false); FLACGPU_LAUNCH(32, true, false);
+        }
+#undef FLACGPU_LAUNCH
     }
     mark(h, EV_DECODE, st);
     if ((rc = fetch_results(h, n_streams, results, st))) return rc;

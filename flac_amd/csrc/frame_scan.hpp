@@ -11,8 +11,9 @@
 //   k_compact       ordered candidate list (offset, header fields) from the mask.
 //   k_stream_ranges candidate range of every stream.
 //   k_crc16_spans   CRC-16 of the bytes between consecutive candidates; one
-//                   wave per span, lanes take contiguous slices that are joined
-//                   by multiplying with x^(8*len) in GF(2)[x] / 0x18005.
+//                   wave per span, lanes load consecutive 16-byte vectors and
+//                   the partial remainders are joined by table multiplications
+//                   in GF(2)[x] / 0x18005.
 //   k_resolve_*     candidate i is a frame when the CRC-16 of a span that starts
 //                   at i and ends at one of the next kLookahead candidates (or the
 //                   end of the stream) is zero; output range checks.
@@ -301,47 +302,119 @@ __device__ inline uint32_t crc16_shift(uint32_t crc, uint32_t after, const uint1
     return after ? gf_mulmod(crc, gf_xpow8(after, pow2)) : crc;
 }
 
-__device__ inline void crc16_tables(uint16_t *tab, uint16_t *pow2)
+// pow2[k] = x^(8 * 2^k) mod P, for gf_xpow8
+__device__ inline void crc16_pow_table(uint16_t *pow2)
 {
-    // tab[i] = i * x^16 mod P  (byte-at-a-time table); pow2[k] = x^(8 * 2^k) mod P
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-        uint32_t d = i << 8;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) d = (d & 0x8000) ? ((d << 1) ^ 0x18005) : (d << 1);
-        tab[i] = (uint16_t)d;
-    }
     if (threadIdx.x == 0) {
         uint32_t p = 0x100;  // x^8
         for (int k = 0; k < 32; ++k) { pow2[k] = (uint16_t)p; p = gf_mulmod(p, p); }
     }
 }
 
-// One wave per candidate: CRC-16 of [goff[r], next) where next is the following
-// candidate of the same stream or the end of the stream.
-__global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__ in, const StreamDev *__restrict__ streams,
-                                                     CandArrays c, uint32_t n_cand)
+// Lookup tables of k_crc16_spans, built once per handle (uint16 entries):
+//   piece[m][v]  (16 x 256)  v * x^(16 + 8m): byte v with m more bytes behind it in its 16-byte piece
+//   skip[h][v]   (2 x 256)   multiplication of a 16-bit remainder by x^(8 * 1024), split by byte
+//   lanew[l]     (64)        x^(8 * 16 * (63 - l))
+//   remw[r]      (16)        x^(8 * r)
+constexpr int kCrcPiece = 0, kCrcSkip = 16 * 256, kCrcLane = kCrcSkip + 512, kCrcRem = kCrcLane + 64,
+              kCrcTableEntries = kCrcRem + 16;
+
+__global__ void k_crc16_build_tables(uint16_t *t)
 {
-    __shared__ uint16_t s_tab[256];
     __shared__ uint16_t s_pow2[32];
-    crc16_tables(s_tab, s_pow2);
+    crc16_pow_table(s_pow2);
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t r = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (r >= n_cand) return;
-    const uint64_t a = c.goff[r];
-    const uint32_t si = c.stream[r];
-    uint64_t b = streams[si].in_off + streams[si].in_len;
-    if (r + 1 < n_cand && c.stream[r + 1] == si) b = c.goff[r + 1];
-    const uint32_t len = (uint32_t)(b - a);
-    const uint32_t slice = (len + 63) / 64;
-    const uint32_t s0 = min(lane * slice, len), s1 = min(s0 + slice, len);
-    uint32_t crc = 0;
-    const uint8_t *p = in + a;
-    for (uint32_t i = s0; i < s1; ++i) crc = ((crc << 8) & 0xFFFF) ^ s_tab[(crc >> 8) ^ p[i]];
-    crc = crc16_shift(crc, len - s1, s_pow2);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries; i += blockDim.x) {
+        uint32_t v;
+        if (i < (uint32_t)kCrcSkip) {
+            const uint32_t m = i >> 8, byte = i & 255;
+            v = gf_mulmod(byte, gf_xpow8(2 + m, s_pow2));             // byte * x^(16 + 8m)
+        } else if (i < (uint32_t)kCrcLane) {
+            const uint32_t hsel = (i - kCrcSkip) >> 8, byte = i & 255;
+            v = gf_mulmod(hsel ? byte << 8 : byte, gf_xpow8(1024, s_pow2));
+        } else if (i < (uint32_t)kCrcRem) {
+            v = gf_xpow8(16 * (63 - (i - kCrcLane)), s_pow2);
+        } else {
+            v = gf_xpow8(i - kCrcRem, s_pow2);
+        }
+        t[i] = (uint16_t)v;
+    }
+}
+
+// CRC-16 of the 16 bytes of a vector taken as a message of its own (init 0): sixteen independent lookups.
+__device__ inline uint32_t crc16_piece(const uint4 v, const uint16_t *piece)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t c = 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) crc ^= __shfl_xor(crc, d);
-    if (lane == 0) { c.segcrc[r] = (uint16_t)crc; c.seglen[r] = len; }
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        c ^= piece[(15 - k) * 256 + byte];
+    }
+    return c;
+}
+
+// CRC-16 of every candidate span [goff[r], next), next = the following candidate of the
+// same stream or the end of the stream.  One wave per span at a time (waves stride over
+// the spans); lanes load consecutive 16-byte vectors (1 KiB per wave per step), reduce
+// each to its remainder with table lookups, and carry it over the 1 KiB stride by a
+// table multiplication; the 64 partial remainders are weighted by lane and XOR-ed.
+__global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__ in, const StreamDev *__restrict__ streams,
+                                                     CandArrays c, uint32_t n_cand, const uint16_t *__restrict__ tables)
+{
+    __shared__ __align__(16) uint16_t s_t[kCrcTableEntries];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries / 2; i += blockDim.x)
+        reinterpret_cast<uint32_t *>(s_t)[i] = reinterpret_cast<const uint32_t *>(tables)[i];
+    __syncthreads();
+    const uint16_t *piece = s_t + kCrcPiece, *skip = s_t + kCrcSkip;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t lanew = s_t[kCrcLane + lane];
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_cand; r += waves) {
+        const uint64_t a = c.goff[r];
+        const uint32_t si = c.stream[r];
+        uint64_t b = streams[si].in_off + streams[si].in_len;
+        if (r + 1 < n_cand && c.stream[r + 1] == si) b = c.goff[r + 1];
+        const uint64_t A = a & ~(uint64_t)15;
+        const uint32_t lead = (uint32_t)(a - A);
+        const uint32_t nfull = (uint32_t)((b - A) >> 4), rem = (uint32_t)((b - A) & 15);
+        const uint32_t steps = (nfull + 63) >> 6, pad = steps * 64 - nfull;
+        const uint4 *src = reinterpret_cast<const uint4 *>(in + A);
+        uint32_t acc = 0;
+        for (uint32_t t = 0; t < steps; ++t) {
+            const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)pad;
+            uint32_t pc = 0;
+            if (j >= 0) {
+                uint4 v = src[j];
+                if (j == 0 && lead) {   // bytes before the span count as zeros (no effect with init 0)
+                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int32_t nz = (int32_t)lead - 4 * i;
+                        if (nz >= 4) w[i] = 0;
+                        else if (nz > 0) w[i] &= 0xFFFFFFFFu << (8 * nz);
+                    }
+                    v = uint4{w[0], w[1], w[2], w[3]};
+                }
+                pc = crc16_piece(v, piece);
+            }
+            acc = skip[acc & 0xFF] ^ skip[256 + (acc >> 8)] ^ pc;
+        }
+        acc = gf_mulmod(acc, lanew);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc ^= __shfl_xor(acc, d);
+        if (lane == 0) {
+            const uint32_t crc = gf_mulmod(acc, s_t[kCrcRem + rem]);
+            // the bytes after the last whole vector (at most 15), byte at a time:
+            // crc = (crc << 8) ^ T[(crc >> 8) ^ byte] with T[v] = v * x^16 = piece[0][v]
+            uint32_t tcrc = 0;
+            const uint64_t t0 = A + ((uint64_t)nfull << 4);
+            for (uint64_t g = (t0 > a ? t0 : a); g < b; ++g)
+                tcrc = ((tcrc << 8) & 0xFFFF) ^ piece[(tcrc >> 8) ^ in[g]];
+            c.segcrc[r] = (uint16_t)(crc ^ tcrc);
+            c.seglen[r] = (uint32_t)(b - a);
+        }
+    }
 }
 
 // --------------------------------------------------------------- resolve ---
@@ -375,9 +448,8 @@ __global__ void k_resolve_fast(StreamDev *streams, CandArrays c, uint32_t n_cand
 // the candidates in order, trying up to kLookahead end points for each.
 __global__ void k_resolve_slow(StreamDev *streams, uint32_t n_streams, CandArrays c)
 {
-    __shared__ uint16_t s_tab[256];
     __shared__ uint16_t s_pow2[32];
-    crc16_tables(s_tab, s_pow2);
+    crc16_pow_table(s_pow2);
     __syncthreads();
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams || !streams[s].pending) return;

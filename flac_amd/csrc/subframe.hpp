@@ -10,9 +10,14 @@
 //              subframe starts.
 //   k_decode   one lane per subframe (frame f, channel c); the lanes of a wave
 //              advance sample by sample in lockstep, so prediction history
-//              lives in registers, stereo decorrelation is a lane exchange, and
-//              the wave stages 32 samples of all its frames in LDS and writes
-//              them out as contiguous runs per frame.
+//              lives in registers (renamed, not moved: the sample loop is
+//              unrolled by the predictor length), stereo decorrelation is a lane
+//              exchange, and the wave stages a tile of samples of all its frames
+//              in LDS and writes it out as contiguous runs per frame.
+//              The kernel is instantiated per predictor length / accumulator
+//              width so that short predictors do not pay the registers of long
+//              ones; every instantiation is launched over the same grid and a
+//              wave runs in exactly one of them.
 // Arithmetic is 32-bit except LPC sums when bps + precision + floor(log2(order))
 // exceeds 32, which accumulate in 64 bits.
 #pragma once
@@ -23,40 +28,65 @@ namespace flacgpu {
 
 // -------------------------------------------------------------- bit reader --
 
-// MSB-first reader over one frame.  Positions are bits from the 4-byte-aligned
-// word at or before the frame's first byte.  Bytes past the end of the frame
-// read as zero.
-struct BitReader {
-    const uint32_t *w;
-    uint32_t full_words;   // words entirely inside [base, frame end)
-    uint32_t tail_bytes;   // valid bytes in word `full_words`
-    uint32_t idx, bit, hi, lo;
+// Every lane walks its own bitstream, so a direct load would touch 64 different
+// cache lines per wave instruction and use 16 bytes of each.  Instead each lane
+// owns a small ring in LDS that the whole wave refills together: four lanes
+// fetch 64 contiguous bytes of one lane's stream (ring_refill), so a wave-wide
+// load reads 16 streams x 64 bytes in whole 64-byte segments.
+constexpr uint32_t kRingWords = 32;   // ring capacity per lane, in 32-bit words
+constexpr uint32_t kUnitWords = 16;   // refill granule: 64 bytes
+constexpr uint32_t kRingBytesPerWave = kRingWords * 64 * 4;
 
-    __device__ inline uint32_t load(uint32_t i) const
+// MSB-first reader over one lane's bitstream.  Positions are bits from the
+// 64-byte-aligned address at or before the frame's first byte.  Ring word w of
+// the lane sits at ring[(w % kRingWords) * 64] (ring already points at the
+// lane's column), stored big-endian-corrected; the ring holds words
+// [fill - kRingWords, fill).  A word the ring does not hold is read from global
+// memory directly (after a seek, or when a lane outruns the refill schedule).
+// Words past the end of the input buffer read as zero.
+struct BitReader {
+    const uint32_t *gbase;   // global words from the aligned base
+    uint32_t nwords;         // words readable from gbase
+    uint32_t *ring;
+    uint64_t gvec;           // vector (16-byte) index of gbase in the input buffer
+    uint32_t rd;             // next word to fetch into `nx`
+    uint32_t fill;
+    uint32_t bit;            // bits of `hi` already consumed
+    uint32_t hi, lo, nx;     // words rd-3, rd-2, rd-1
+
+    __device__ inline uint32_t fetch(uint32_t w) const
     {
-        if (i < full_words) return __builtin_bswap32(w[i]);
-        if (i == full_words && tail_bytes) {
-            const uint8_t *p = reinterpret_cast<const uint8_t *>(w + i);
-            uint32_t v = 0;
-            for (uint32_t k = 0; k < tail_bytes; ++k) v |= (uint32_t)p[k] << (24 - 8 * k);
-            return v;
-        }
-        return 0;
+        if (w < fill) return ring[(w & (kRingWords - 1)) * 64];
+        return w < nwords ? __builtin_bswap32(gbase[w]) : 0u;
     }
-    __device__ inline void init(const uint8_t *in, uint64_t goff, uint32_t frame_len)
+    __device__ inline void init(const uint8_t *in, uint64_t in_vecs, uint64_t goff, uint32_t *lane_ring)
     {
-        const uint32_t a = (uint32_t)(goff & 3);
-        w = reinterpret_cast<const uint32_t *>(in + (goff - a));
-        full_words = (a + frame_len) >> 2;
-        tail_bytes = (a + frame_len) & 3;
-        idx = bit = hi = lo = 0;
+        const uint64_t b = goff & ~(uint64_t)63;
+        gbase = reinterpret_cast<const uint32_t *>(in + b);
+        gvec = b >> 4;
+        nwords = (uint32_t)min((in_vecs - gvec) * 4, (uint64_t)0xFFFFFFFFu);
+        ring = lane_ring;
+        rd = fill = bit = hi = lo = nx = 0;
+    }
+    __device__ inline void null(uint32_t *lane_ring)
+    {
+        gbase = nullptr; nwords = 0; ring = lane_ring; gvec = 0;
+        rd = fill = bit = hi = lo = nx = 0;
+    }
+    __device__ inline void advance()
+    {
+        hi = lo; lo = nx; nx = fetch(rd); ++rd;
     }
     __device__ inline void seek(uint32_t bitpos)
     {
-        idx = bitpos >> 5; bit = bitpos & 31;
-        hi = load(idx); lo = load(idx + 1);
+        const uint32_t w = bitpos >> 5;
+        bit = bitpos & 31;
+        fill = w & ~(kUnitWords - 1);   // ring restarts at this unit; until the next refill, words come from global memory
+        rd = w;
+        hi = fetch(rd); lo = fetch(rd + 1); nx = fetch(rd + 2);
+        rd += 3;
     }
-    __device__ inline uint32_t pos() const { return idx * 32 + bit; }
+    __device__ inline uint32_t pos() const { return (rd - 3) * 32 + bit; }
     __device__ inline uint32_t peek() const
     {
         return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (32 - bit));
@@ -64,7 +94,7 @@ struct BitReader {
     __device__ inline void skip(uint32_t n)   // n <= 32
     {
         bit += n;
-        if (bit >= 32) { bit -= 32; ++idx; hi = lo; lo = load(idx + 1); }
+        if (bit >= 32) { bit -= 32; advance(); }
     }
     __device__ inline void skip_long(uint32_t n) { seek(pos() + n); }
     __device__ inline uint32_t read(uint32_t n)   // n <= 32
@@ -81,8 +111,47 @@ struct BitReader {
     }
 };
 
+// Wave-wide refill: every lane whose ring holds 16 or fewer unread words gets its
+// next 64 bytes.  Lane 4i+p fetches vector p of lane i's unit, for four groups of 16
+// lanes in turn.  Must be called by all 64 lanes together.  After the call a
+// participating lane has more than 16 unread words, enough for 16 steps of at most
+// 32 bits each.
+__device__ inline void ring_refill(BitReader &br, bool active, const uint4 *in_vec, uint64_t in_vecs,
+                                   uint32_t *wave_ring, uint32_t lane)
+{
+    if (active && (int32_t)(br.fill - br.rd) < -(int32_t)kUnitWords + 1) br.fill = br.rd & ~(kUnitWords - 1);
+    const bool need = active && (int32_t)(br.fill - br.rd) <= (int32_t)kUnitWords;
+    const uint64_t need_mask = __ballot(need);
+    if (need_mask == 0) return;
+    const uint64_t gv = br.gvec + (br.fill >> 2);
+    const uint32_t info = (br.fill & (kRingWords - 1)) | (need ? 0x80000000u : 0u);
+    const uint32_t p = lane & 3;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (((need_mask >> (16 * g)) & 0xFFFF) == 0) continue;
+        const uint32_t t = 16 * g + (lane >> 2);
+        const uint32_t t_info = (uint32_t)__shfl((int)info, (int)t);
+        const uint64_t t_gv = ((uint64_t)(uint32_t)__shfl((int)(gv >> 32), (int)t) << 32) |
+                              (uint32_t)__shfl((int)(uint32_t)gv, (int)t);
+        if (t_info & 0x80000000u) {
+            const uint64_t v_idx = t_gv + p;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (v_idx < in_vecs) v = in_vec[v_idx];
+            uint32_t *dst = wave_ring + t;
+            const uint32_t slot = (t_info + 4 * p) & (kRingWords - 1);
+            dst[(slot + 0) * 64] = __builtin_bswap32(v.x);
+            dst[(slot + 1) * 64] = __builtin_bswap32(v.y);
+            dst[(slot + 2) * 64] = __builtin_bswap32(v.z);
+            dst[(slot + 3) * 64] = __builtin_bswap32(v.w);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (need) br.fill += kUnitWords;
+}
+
 // Unary-coded count: zeros up to and including the terminating one are consumed.
-// limit: bit position past which the frame has ended (guards the all-zero tail).
+// limit: bit position past which the frame has ended (bounds an all-zero run).
 __device__ inline uint32_t read_unary(BitReader &br, uint32_t limit)
 {
     uint32_t q = 0, w = br.peek();
@@ -106,7 +175,7 @@ __device__ inline int32_t read_rice(BitReader &br, uint32_t k, uint32_t limit)
         q = __clz(w);
         const uint32_t n = q + 1 + k;
         if (n <= 32) {
-            low = k ? (w << (q + 1)) >> (32 - k) : 0;
+            low = __builtin_amdgcn_ubfe(w, 32 - n, k);
             br.skip(n);
         } else {
             br.skip(q + 1);
@@ -172,96 +241,111 @@ __device__ inline bool is_side(uint32_t ch_assign, uint32_t c)
 
 // -------------------------------------------------------------------- skim --
 
-// Walks one whole subframe without reconstructing it.  Returns a kFrame* status.
-__device__ inline int skim_subframe(BitReader &br, uint32_t bps, uint32_t bs, uint32_t limit)
-{
-    SubHdr h;
-    int rc = read_subframe_header(br, bps, bs, limit, h);
-    if (rc) return rc;
-    if (h.kind == 0) { br.skip(h.sbps); return br.pos() > limit ? kFrameTruncated : kFrameOK; }
-    if (h.kind == 1) {
-        const uint64_t n = (uint64_t)bs * h.sbps;
-        if (br.pos() + n > limit) return kFrameTruncated;
-        br.skip_long((uint32_t)n);
-        return kFrameOK;
-    }
-    if (br.pos() + (uint64_t)h.order * h.sbps > limit) return kFrameTruncated;
-    br.skip_long(h.order * h.sbps);
-    if (h.lpc) {
-        const uint32_t pc = br.read(4);
-        if (pc == 15) return kFrameBadSubframe;
-        const int32_t shift = br.read_signed(5);
-        if (shift < 0) return kFrameBadSubframe;
-        br.skip_long(h.order * (pc + 1));
-    }
-    const uint32_t method = br.read(2);
-    if (method > 1) return kFrameBadSubframe;
-    const uint32_t pbits = method ? 5 : 4, esc = method ? 31 : 15;
-    const uint32_t po = br.read(4);
-    if (br.pos() > limit) return kFrameTruncated;
-    if (bs & ((1u << po) - 1)) return kFrameBadSubframe;
-    const uint32_t psamp = bs >> po;
-    if (psamp < h.order) return kFrameBadSubframe;
-    uint32_t parts_left = 1u << po, part_rem = 0, k = 0;
-    uint32_t first = 1;
-    for (;;) {
-        if (part_rem == 0) {
-            if (br.pos() > limit) return kFrameTruncated;
-            if (parts_left == 0) break;
-            --parts_left;
-            uint32_t cnt = psamp - (first ? h.order : 0);
-            first = 0;
-            k = br.read(pbits);
-            if (k == esc) {
-                const uint32_t wd = br.read(5);
-                const uint64_t n = (uint64_t)cnt * wd;
-                if (br.pos() + n > limit) return kFrameTruncated;
-                br.skip_long((uint32_t)n);
-                cnt = 0;
-            }
-            part_rem = cnt;
-        } else {
-            skip_rice(br, k, limit);
-            --part_rem;
-        }
-    }
-    return kFrameOK;
-}
-
 // One lane per candidate frame r in [r_begin, r_end); C channels.  Records
 // subpos[r*8 + c] for every channel and turns frames that fail to parse into
-// their error status.
-__global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, CandArrays c, uint32_t r_begin,
-                                              uint32_t r_end, uint32_t C)
+// their error status.  The lanes of a wave run a small state machine in
+// lockstep, one step per iteration (a header, a partition parameter, or the
+// length of one Rice code), with a ring refill every 16 steps.
+__global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, uint64_t in_vecs, CandArrays c,
+                                              uint32_t r_begin, uint32_t r_end, uint32_t C)
 {
+    __shared__ __align__(16) uint32_t s_ring[4 * kRingWords * 64];
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t *wave_ring = s_ring + (threadIdx.x >> 6) * (kRingWords * 64);
     const uint32_t r = r_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= r_end) return;
-    if (c.status[r] != kFrameOK) return;
-    const uint32_t info = c.info[r];
-    const uint32_t bs = info_bs(info), bps = info_bps(info), ca = info_ca(info);
-    const uint64_t goff = c.goff[r];
-    const uint32_t len = c.len[r];
+    bool active = r < r_end;
+    if (active) active = c.status[r] == kFrameOK;
     BitReader br;
-    br.init(in, goff, len);
-    const uint32_t a = (uint32_t)(goff & 3);
-    const uint32_t limit = (a + len) * 8;   // first bit after the frame
-    br.seek((a + info_hl(info)) * 8);
-    int rc = kFrameOK;
-    for (uint32_t ch = 0; ch < C; ++ch) {
-        c.subpos[(uint64_t)r * 8 + ch] = br.pos();
-        if (ch + 1 == C) break;   // the last subframe is checked by its decode lane
-        rc = skim_subframe(br, bps + (is_side(ca, ch) ? 1 : 0), bs, limit);
-        if (rc) break;
+    br.null(wave_ring + lane);
+    uint32_t bs = 0, bps = 0, ca = 0, limit = 0;
+    if (active) {
+        const uint32_t info = c.info[r];
+        bs = info_bs(info); bps = info_bps(info); ca = info_ca(info);
+        const uint64_t goff = c.goff[r];
+        br.init(in, in_vecs, goff, wave_ring + lane);
+        const uint32_t a = (uint32_t)(goff & 63);
+        limit = (a + c.len[r]) * 8;   // first bit after the frame
+        br.seek((a + info_hl(info)) * 8);
     }
-    if (rc) c.status[r] = rc;
+    enum { S_HDR, S_PART, S_RICE, S_DONE };
+    uint32_t state = active ? S_HDR : S_DONE;
+    uint32_t ch = 0, order = 0, psamp = 0, parts_left = 0, part_rem = 0, k = 0, pbits = 4, esc = 15;
+    bool first_part = true;
+    int rc = kFrameOK;
+    const uint4 *in_vec = reinterpret_cast<const uint4 *>(in);
+
+    while (__any(state != S_DONE)) {
+        ring_refill(br, state != S_DONE, in_vec, in_vecs, wave_ring, lane);
+        for (int step = 0; step < 16; ++step) {
+            if (state == S_RICE) {
+                skip_rice(br, k, limit);
+                if (--part_rem == 0) state = S_PART;
+            } else if (state == S_PART) {
+                if (br.pos() > limit) { rc = kFrameTruncated; state = S_DONE; }
+                else if (parts_left == 0) { ++ch; state = S_HDR; }
+                else {
+                    --parts_left;
+                    uint32_t cnt = psamp - (first_part ? order : 0);
+                    first_part = false;
+                    k = br.read(pbits);
+                    if (k == esc) {
+                        const uint32_t wd = br.read(5);
+                        const uint64_t n = (uint64_t)cnt * wd;
+                        if (br.pos() + n > limit) { rc = kFrameTruncated; state = S_DONE; }
+                        else br.skip_long((uint32_t)n);
+                        cnt = 0;
+                    }
+                    part_rem = cnt;
+                    if (cnt && state != S_DONE) state = S_RICE;
+                }
+            } else if (state == S_HDR) {
+                c.subpos[(uint64_t)r * 8 + ch] = br.pos();
+                if (ch + 1 == C) { state = S_DONE; }   // the last subframe is checked by its decode lane
+                else {
+                    SubHdr h;
+                    rc = read_subframe_header(br, bps + (is_side(ca, ch) ? 1 : 0), bs, limit, h);
+                    if (rc) state = S_DONE;
+                    else if (h.kind == 0) {
+                        br.skip(h.sbps);
+                        if (br.pos() > limit) { rc = kFrameTruncated; state = S_DONE; } else ++ch;
+                    } else if (h.kind == 1) {
+                        const uint64_t n = (uint64_t)bs * h.sbps;
+                        if (br.pos() + n > limit) { rc = kFrameTruncated; state = S_DONE; }
+                        else { br.skip_long((uint32_t)n); ++ch; }
+                    } else {
+                        order = h.order;
+                        if (br.pos() + (uint64_t)order * h.sbps > limit) { rc = kFrameTruncated; state = S_DONE; }
+                        else {
+                            br.skip_long(order * h.sbps);
+                            if (h.lpc) {
+                                const uint32_t pc = br.read(4);
+                                const int32_t shift = br.read_signed(5);
+                                if (pc == 15 || shift < 0) { rc = kFrameBadSubframe; state = S_DONE; }
+                                else br.skip_long(order * (pc + 1));
+                            }
+                            if (state != S_DONE) {
+                                const uint32_t method = br.read(2);
+                                const uint32_t po = br.read(4);
+                                pbits = method ? 5 : 4; esc = method ? 31 : 15;
+                                psamp = bs >> po;
+                                if (method > 1 || (bs & ((1u << po) - 1)) || psamp < order) { rc = kFrameBadSubframe; state = S_DONE; }
+                                else if (br.pos() > limit) { rc = kFrameTruncated; state = S_DONE; }
+                                else { parts_left = 1u << po; part_rem = 0; first_part = true; state = S_PART; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (active && rc) c.status[r] = rc;
 }
 
 // ------------------------------------------------------------------ decode --
 
-constexpr int kTile = 32;   // samples staged in LDS between write-outs
-
 struct DecodeParams {
     const uint8_t *in;
+    uint64_t in_vecs;      // 16-byte vectors readable from `in`
     uint8_t *out;
     const StreamDev *streams;
     CandArrays c;
@@ -270,31 +354,117 @@ struct DecodeParams {
     uint32_t B;            // bytes per sample in the output
 };
 
-// The sample loop of one wave, specialised on the largest predictor order among
-// its lanes (MAXORD) and on whether any lane needs 64-bit sums (WIDE).
-template <int MAXORD, bool WIDE>
-__device__ inline void decode_loop(BitReader &br, const SubHdr &h, bool active, bool dwords, uint32_t bs,
-                                   uint32_t bs_max, uint32_t limit, uint32_t ca, uint32_t ch, uint32_t C, uint32_t B,
-                                   uint32_t frame_in_wave, uint32_t frames_in_wave, uint8_t *tile, uint32_t row_stride,
-                                   uint8_t *dst_row /* this frame's output */, const uint64_t *s_dst,
-                                   const uint32_t *s_bs, int &status)
+__device__ inline uint32_t wave_max_u32(uint32_t v)
 {
-    int32_t coef[MAXORD], hist[MAXORD];
 #pragma unroll
-    for (int j = 0; j < MAXORD; ++j) { coef[j] = 0; hist[j] = 0; }
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return v;
+}
+
+// Predictor classes: a wave runs in the smallest class that holds the largest
+// order among its lanes.  U = history ring size and unroll factor, NT = taps.
+__device__ inline int order_class(uint32_t maxord) { return maxord <= 4 ? 4 : maxord <= 12 ? 12 : 32; }
+__host__ __device__ constexpr int class_unroll(int nt) { return nt <= 16 ? 16 : 32; }
+
+constexpr uint32_t kTile = 32;   // samples staged in LDS between write-outs
+
+// LDS bytes one wave needs: the sample tile (rows padded by 4 bytes so that rows
+// start on different banks) plus per-frame destination and block size.
+__host__ __device__ inline uint32_t decode_wave_lds(uint32_t C, uint32_t B)
+{
+    const uint32_t F = 64 / C, row_stride = kTile * C * B + 4;
+    return kRingBytesPerWave + ((F * row_stride + 15) & ~15u) + F * 16;
+}
+
+// One lane per (frame, channel); a wave holds floor(64 / C) frames.
+// NT: predictor taps evaluated per sample (4, 12 or 32).  WIDE: 64-bit sums.
+// STEREO16: C == 2 and B == 2, the pair of lanes writes one packed word per sample.
+//
+// Samples are processed in groups of U.  A group in which every lane is in the
+// middle of a Rice partition (or constant / finished) runs the unrolled fast
+// body: no partition, warm-up or end-of-block tests, history renamed instead of
+// moved.  Any other group (warm-up samples, coefficient parsing, partition
+// boundary inside the group, escape-coded or verbatim data, the tail of a block)
+// runs the generic rolled body with a shift-register history.
+template <int NT, bool WIDE, bool STEREO16>
+__global__ __launch_bounds__(256) void k_decode(DecodeParams p)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int U = class_unroll(NT);
+    const uint32_t C = STEREO16 ? 2u : p.C, B = STEREO16 ? 2u : p.B;
+    const uint32_t CB = C * B;
+    const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    const uint32_t F = 64 / C;
+    const uint32_t row_stride = kTile * CB + 4;
+    const uint32_t wave_bytes = decode_wave_lds(C, B);
+    uint32_t *wave_ring = reinterpret_cast<uint32_t *>(smem + wave_in_block * wave_bytes);
+    uint8_t *tile = smem + wave_in_block * wave_bytes + kRingBytesPerWave;
+    uint64_t *s_dst = reinterpret_cast<uint64_t *>(tile + ((F * row_stride + 15) & ~15u));
+    uint32_t *s_bs = reinterpret_cast<uint32_t *>(s_dst + F);
+
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    const uint32_t fl = lane / C, ch = lane - fl * C;
+    const uint32_t r = p.r_begin + wave * F + fl;
+    bool active = fl < F && r < p.r_end;
+    int status = kFrameOK;
+    if (active) status = p.c.status[r];
+    active = active && status == kFrameOK;
+
+    uint32_t bs = 0, ca = 0, limit = 0;
+    SubHdr h;
+    h.kind = 0; h.order = 0; h.lpc = 0; h.wasted = 0; h.sbps = 0;
+    BitReader br;
+    br.null(wave_ring + lane);
+    uint64_t dst = 0;
+    if (active) {
+        const uint32_t info = p.c.info[r];
+        const uint64_t goff = p.c.goff[r];
+        const StreamDev &s = p.streams[p.c.stream[r]];
+        bs = info_bs(info); ca = info_ca(info);
+        limit = ((uint32_t)(goff & 63) + p.c.len[r]) * 8;
+        br.init(p.in, p.in_vecs, goff, wave_ring + lane);
+        br.seek(p.c.subpos[(uint64_t)r * 8 + ch]);
+        const uint64_t first = info_var(info) ? p.c.num[r] : p.c.num[r] * (uint64_t)s.max_bs;
+        dst = reinterpret_cast<uint64_t>(p.out) + s.out_off + first * CB;
+        const int rc = read_subframe_header(br, info_bps(info) + (is_side(ca, ch) ? 1 : 0), bs, limit, h);
+        if (rc) { status = rc; h.kind = 0; h.order = 0; }
+    }
+    // predictor precision is stored after the warm-up samples: look ahead for the accumulator width
+    bool need_wide = false;
+    if (active && status == kFrameOK && h.kind == 2 && h.lpc) {
+        BitReader t = br;
+        t.skip_long(h.order * h.sbps);
+        const uint32_t prec = t.read(4) + 1;
+        need_wide = (h.sbps + prec + (31 - __clz(h.order))) > 32;
+    }
+    const uint32_t maxord = wave_max_u32(active && status == kFrameOK ? h.order : 0);
+    const bool any_wide = __any(need_wide);
+    // a wave is decoded by exactly one instantiation: narrow 4 / 12 / 32 taps, wide 12 / 32 taps
+    const int cls = any_wide ? (maxord <= 12 ? 12 : 32) : order_class(maxord);
+    if (cls != NT || any_wide != WIDE) return;
+
+    const uint32_t bs_max = wave_max_u32(active ? bs : 0);
+    if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; }
+    // whole-dword write-out needs every frame's destination 4-byte aligned
+    const bool dwords = (CB & 3) == 0 && !__any(active && (dst & 3));
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- per-lane decoder state --------------------------------------------------------
+    int32_t coef[NT];
+    int32_t ring[U];    // ring[i] = most recent sample n with n % U == i
+#pragma unroll
+    for (int j = 0; j < NT; ++j) coef[j] = 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) ring[j] = 0;
     uint32_t shift = 0;
-    bool wide = false;
-    uint32_t kind = active ? h.kind : 0;
+    bool wide = false, started = false;
+    const uint32_t kind = active ? h.kind : 0;
     const uint32_t order = h.order;
     int32_t constval = 0;
     if (active && kind == 0) constval = br.read_signed(h.sbps);
-    // residual partition state
     uint32_t pbits = 4, esc = 15, psamp = 0, parts_left = 0, part_rem = 0, k = 0, escw = 0;
-    bool escaped = false;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t row_bytes = kTile * C * B;
+    bool escaped = false, first_part = true;
 
-    bool first_part = true;
     // Reads what follows the warm-up samples: LPC parameters (or the fixed
     // polynomial as coefficients) and the residual coding header.
     auto start_residual = [&]() {
@@ -305,7 +475,7 @@ __device__ inline void decode_loop(BitReader &br, const SubHdr &h, bool active, 
             shift = (uint32_t)sh & 31;
             const uint32_t prec = pc + 1;
 #pragma unroll
-            for (int j = 0; j < MAXORD; ++j)
+            for (int j = 0; j < NT; ++j)
                 if ((uint32_t)j < order) coef[j] = br.read_signed(prec);
             wide = (h.sbps + prec + (31 - __clz(order))) > 32;
         } else {
@@ -336,179 +506,168 @@ __device__ inline void decode_loop(BitReader &br, const SubHdr &h, bool active, 
             if (br.pos() > limit) status = kFrameTruncated;
         }
     };
-
-    for (uint32_t n0 = 0; n0 < bs_max; n0 += kTile) {
-        const uint32_t n1 = min(n0 + (uint32_t)kTile, bs_max);
-        for (uint32_t n = n0; n < n1; ++n) {
-            const bool live = active && n < bs && status == kFrameOK;
-            int32_t v = constval;
-            bool predicted = false;
-            if (live && kind != 0) {
-                if (kind == 1 || n < order) {
-                    v = br.read_signed(h.sbps);
-                } else {
-                    if (n == order) start_residual();
-                    if (part_rem == 0) next_partition();
-                    if (status == kFrameOK && part_rem == 0) status = kFrameTruncated;
-                    if (status == kFrameOK) {
-                        --part_rem;
-                        v = escaped ? br.read_signed(escw) : read_rice(br, k, limit);
-                        predicted = true;
-                    }
-                }
+    // Stereo decorrelation + staging of one sample into the LDS tile.  `col` = sample index inside the tile.
+    auto emit = [&](int32_t v, bool live, uint32_t col) {
+        uint32_t o = (uint32_t)v << h.wasted;
+        if (STEREO16) {
+            const uint32_t q = (uint32_t)__shfl_xor((int)o, 1);
+            const uint32_t a = ch == 0 ? o : q, b = ch == 0 ? q : o;   // channel 0 / channel 1 as coded
+            uint32_t L = a, R = b;
+            if (ca == 8) R = a - b;
+            else if (ca == 9) L = a + b;
+            else if (ca == 10) {
+                const uint32_t mm = (a << 1) | (b & 1);
+                L = (uint32_t)((int32_t)(mm + b) >> 1);
+                R = (uint32_t)((int32_t)(mm - b) >> 1);
             }
-            // prediction: every lane evaluates the full MAXORD-tap sum; unused taps are zero
-            int32_t pred;
-            if (WIDE) {
-                int64_t sum = 0;
-#pragma unroll
-                for (int j = 0; j < MAXORD; ++j) sum += (int64_t)coef[j] * (int64_t)hist[j];
-                pred = wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum) >> shift;
-            } else {
-                uint32_t sum = 0;
-#pragma unroll
-                for (int j = 0; j < MAXORD; ++j) sum += (uint32_t)coef[j] * (uint32_t)hist[j];
-                pred = (int32_t)sum >> shift;
-            }
-            if (predicted) v = (int32_t)((uint32_t)v + (uint32_t)pred);
-#pragma unroll
-            for (int j = MAXORD - 1; j > 0; --j) hist[j] = hist[j - 1];
-            hist[0] = v;
-
-            uint32_t o = (uint32_t)v << h.wasted;
+            if (live && ch == 0)
+                *reinterpret_cast<uint32_t *>(tile + fl * row_stride + col * 4) = (L & 0xFFFFu) | (R << 16);
+        } else {
             if (C == 2) {
-                const uint32_t p = (uint32_t)__shfl_xor((int)o, 1);
-                if (ca == 8) { if (ch == 1) o = p - o; }
-                else if (ca == 9) { if (ch == 0) o = o + p; }
+                const uint32_t q = (uint32_t)__shfl_xor((int)o, 1);
+                if (ca == 8) { if (ch == 1) o = q - o; }
+                else if (ca == 9) { if (ch == 0) o = o + q; }
                 else if (ca == 10) {
-                    const uint32_t m = ch == 0 ? o : p, s = ch == 0 ? p : o;
+                    const uint32_t m = ch == 0 ? o : q, s = ch == 0 ? q : o;
                     const uint32_t mm = (m << 1) | (s & 1);
                     o = ch == 0 ? (uint32_t)((int32_t)(mm + s) >> 1) : (uint32_t)((int32_t)(mm - s) >> 1);
                 }
             }
             if (live) {
-                uint8_t *t = tile + frame_in_wave * row_stride + ((n - n0) * C + ch) * B;
+                uint8_t *t = tile + fl * row_stride + (col * C + ch) * B;
                 if (B == 2) *reinterpret_cast<uint16_t *>(t) = (uint16_t)o;
                 else if (B == 4) *reinterpret_cast<uint32_t *>(t) = o;
                 else if (B == 3) { t[0] = (uint8_t)o; t[1] = (uint8_t)(o >> 8); t[2] = (uint8_t)(o >> 16); }
                 else t[0] = (uint8_t)o;
             }
         }
-        // write the staged samples of every frame of this wave: rows of up to kTile*C*B bytes
+    };
+    // Writes the staged samples [n0, n0 + kTile) of every frame of this wave as runs of up to kTile*C*B bytes.
+    auto flush = [&](uint32_t n0) {
         __builtin_amdgcn_wave_barrier();
+        const uint32_t row_bytes = kTile * CB;
         if (dwords) {
             const uint32_t row_words = row_bytes >> 2;
-            for (uint32_t i = lane; i < frames_in_wave * row_words; i += 64) {
+            for (uint32_t i = lane; i < F * row_words; i += 64) {
                 const uint32_t f = i / row_words, col = i - f * row_words;
                 const uint32_t fbs = s_bs[f];
-                const uint32_t valid = fbs > n0 ? min((uint32_t)kTile, fbs - n0) * C * B : 0;
-                if (col * 4 < valid) {
-                    const uint32_t val = *reinterpret_cast<const uint32_t *>(tile + f * row_stride + col * 4);
-                    *reinterpret_cast<uint32_t *>(s_dst[f] + (uint64_t)n0 * C * B + col * 4) = val;
-                }
+                const uint32_t valid = fbs > n0 ? min(kTile, fbs - n0) * CB : 0;
+                if (col * 4 < valid)
+                    *reinterpret_cast<uint32_t *>(s_dst[f] + (uint64_t)n0 * CB + col * 4) =
+                        *reinterpret_cast<const uint32_t *>(tile + f * row_stride + col * 4);
             }
         } else {
-            for (uint32_t i = lane; i < frames_in_wave * row_bytes; i += 64) {
+            for (uint32_t i = lane; i < F * row_bytes; i += 64) {
                 const uint32_t f = i / row_bytes, col = i - f * row_bytes;
                 const uint32_t fbs = s_bs[f];
-                const uint32_t valid = fbs > n0 ? min((uint32_t)kTile, fbs - n0) * C * B : 0;
-                if (col < valid) *reinterpret_cast<uint8_t *>(s_dst[f] + (uint64_t)n0 * C * B + col) = tile[f * row_stride + col];
+                const uint32_t valid = fbs > n0 ? min(kTile, fbs - n0) * CB : 0;
+                if (col < valid) *reinterpret_cast<uint8_t *>(s_dst[f] + (uint64_t)n0 * CB + col) = tile[f * row_stride + col];
             }
         }
         __builtin_amdgcn_wave_barrier();
-    }
-    // a predicted subframe made only of warm-up samples still carries its parameters
-    if (active && status == kFrameOK && kind == 2 && order >= bs) { start_residual(); next_partition(); }
-    (void)dst_row;
-}
+    };
 
-__device__ inline uint32_t wave_max_u32(uint32_t v)
-{
+    // One extra group runs past the end of the block when some lane's subframe is all warm-up
+    // samples: its predictor parameters still have to be consumed.
+    ring_refill(br, active && status == kFrameOK, reinterpret_cast<const uint4 *>(p.in), p.in_vecs, wave_ring, lane);
+    const bool trailing = __any(active && status == kFrameOK && kind == 2 && order >= bs);
+    const uint32_t n_end = ((bs_max + U - 1) / U) * U + (trailing ? U : 0);
+    for (uint32_t n0 = 0; n0 < n_end; n0 += U) {
+        const uint32_t tile_n0 = n0 & ~(kTile - 1);
+        ring_refill(br, active && status == kFrameOK, reinterpret_cast<const uint4 *>(p.in), p.in_vecs, wave_ring, lane);
+        const bool on = active && status == kFrameOK && n0 < bs;
+        if (on && kind == 2 && started && part_rem == 0) next_partition();
+        if (on && br.pos() > limit) status = kFrameTruncated;
+        const bool rice_on = on && kind == 2 && status == kFrameOK;
+        const bool unstarted = active && status == kFrameOK && kind == 2 && !started;
+        const bool simple = unstarted ? false
+                                      : (!on || kind == 0 ||
+                                         (rice_on && !escaped && part_rem >= (uint32_t)U && n0 + U <= bs));
+        if (__all(simple)) {
+            // ---- fast group: U Rice codes per lane, history renamed -------------------------
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
-    return v;
-}
-
-// One lane per (frame, channel); a wave holds floor(64 / C) frames.
-__global__ __launch_bounds__(256) void k_decode(DecodeParams p)
-{
-    extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t C = p.C, B = p.B;
-    const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
-    const uint32_t F = 64 / C;                      // frames per wave
-    const uint32_t row_stride = kTile * C * B + 4;  // +4: rows start on different LDS banks
-    const uint32_t wave_bytes = ((F * row_stride + 15) & ~15u) + F * 16;
-    uint8_t *tile = smem + wave_in_block * wave_bytes;
-    uint64_t *s_dst = reinterpret_cast<uint64_t *>(tile + ((F * row_stride + 15) & ~15u));
-    uint32_t *s_bs = reinterpret_cast<uint32_t *>(s_dst + F);
-
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-    const uint32_t fl = lane / C, ch = lane - fl * C;
-    const uint32_t r = p.r_begin + wave * F + fl;
-    bool active = fl < F && r < p.r_end;
-    int status = kFrameOK;
-    if (active) status = p.c.status[r];
-    active = active && status == kFrameOK;
-
-    uint32_t bs = 0, ca = 0, limit = 0;
-    SubHdr h;
-    h.kind = 0; h.order = 0; h.lpc = 0; h.wasted = 0; h.sbps = 0;
-    BitReader br;
-    br.w = nullptr; br.full_words = 0; br.tail_bytes = 0; br.idx = br.bit = br.hi = br.lo = 0;
-    uint64_t dst = 0;
-    if (active) {
-        const uint32_t info = p.c.info[r];
-        const uint64_t goff = p.c.goff[r];
-        const uint32_t len = p.c.len[r];
-        const StreamDev &s = p.streams[p.c.stream[r]];
-        bs = info_bs(info); ca = info_ca(info);
-        const uint32_t a = (uint32_t)(goff & 3);
-        limit = (a + len) * 8;
-        br.init(p.in, goff, len);
-        br.seek(p.c.subpos[(uint64_t)r * 8 + ch]);
-        const uint64_t first = info_var(info) ? p.c.num[r] : p.c.num[r] * (uint64_t)s.max_bs;
-        dst = reinterpret_cast<uint64_t>(p.out) + s.out_off + first * C * B;
-        const int rc = read_subframe_header(br, info_bps(info) + (is_side(ca, ch) ? 1 : 0), bs, limit, h);
-        if (rc) { status = rc; h.kind = 0; h.order = 0; }
+            for (int P = 0; P < U; ++P) {
+                int32_t v = constval;
+                if (rice_on) v = read_rice(br, k, limit);
+                int32_t pred;
+                if (WIDE) {
+                    int64_t sum = 0;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) sum += (int64_t)coef[j] * (int64_t)ring[(P + U - 1 - j) % U];
+                    pred = wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum) >> shift;
+                } else {
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) sum += (uint32_t)coef[j] * (uint32_t)ring[(P + U - 1 - j) % U];
+                    pred = (int32_t)sum >> shift;
+                }
+                if (rice_on) v = (int32_t)((uint32_t)v + (uint32_t)pred);
+                ring[P] = v;
+                emit(v, on, n0 + P - tile_n0);
+            }
+            if (rice_on) part_rem -= U;
+        } else {
+            // ---- generic group: one sample at a time, shift-register history ----------------
+            int32_t hist[NT];   // hist[j] = sample n-1-j
+#pragma unroll
+            for (int j = 0; j < NT; ++j) hist[j] = ring[U - 1 - j];
+            for (uint32_t n = n0; n < n0 + U; ++n) {
+                const bool ok = active && status == kFrameOK;
+                const bool live = ok && n < bs;
+                if (ok && kind == 2 && !started && n >= order) {
+                    start_residual();
+                    started = true;
+                    if (n >= bs) next_partition();
+                }
+                int32_t v = constval;
+                bool predicted = false;
+                if (live && kind != 0 && status == kFrameOK) {
+                    if (kind == 1 || n < order) {
+                        v = br.read_signed(h.sbps);
+                    } else {
+                        if (part_rem == 0) {
+                            next_partition();
+                            if (status == kFrameOK && part_rem == 0) status = kFrameTruncated;
+                        }
+                        if (status == kFrameOK) {
+                            --part_rem;
+                            v = escaped ? br.read_signed(escw) : read_rice(br, k, limit);
+                            predicted = true;
+                        }
+                    }
+                }
+                int32_t pred;
+                if (WIDE) {
+                    int64_t sum = 0;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) sum += (int64_t)coef[j] * (int64_t)hist[j];
+                    pred = wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum) >> shift;
+                } else {
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) sum += (uint32_t)coef[j] * (uint32_t)hist[j];
+                    pred = (int32_t)sum >> shift;
+                }
+                if (predicted) v = (int32_t)((uint32_t)v + (uint32_t)pred);
+#pragma unroll
+                for (int j = NT - 1; j > 0; --j) hist[j] = hist[j - 1];
+                hist[0] = v;
+                emit(v, live && status == kFrameOK, n - tile_n0);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ring[U - 1 - j] = hist[j];
+        }
+        const uint32_t done = n0 + U;
+        if ((done & (kTile - 1)) == 0 || done >= n_end) { if (tile_n0 < bs_max) flush(tile_n0); }
     }
-    if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; }
-    // predictor precision is stored after the warm-up samples: look ahead for the accumulator width
-    bool need_wide = false;
-    if (active && status == kFrameOK && h.kind == 2 && h.lpc) {
-        BitReader t = br;
-        t.skip_long(h.order * h.sbps);
-        const uint32_t prec = t.read(4) + 1;
-        need_wide = (h.sbps + prec + (31 - __clz(h.order))) > 32;
-    }
-    const uint32_t maxord = wave_max_u32(active && status == kFrameOK ? h.order : 0);
-    const uint32_t bs_max = wave_max_u32(active ? bs : 0);
-    const bool any_wide = __any(need_wide);
-    // whole-dword write-out needs every frame's destination 4-byte aligned
-    const bool dwords = ((C * B) & 3) == 0 && !__any(active && (dst & 3));
-    __builtin_amdgcn_wave_barrier();
-
-#define FLACGPU_DECODE(MO, W)                                                                                       \
-    decode_loop<MO, W>(br, h, active, dwords, bs, bs_max, limit, ca, ch, C, B, fl, F, tile, row_stride, nullptr, \
-                       s_dst, s_bs, status)
-    if (!any_wide) {
-        if (maxord <= 4) FLACGPU_DECODE(4, false);
-        else if (maxord <= 8) FLACGPU_DECODE(8, false);
-        else if (maxord <= 12) FLACGPU_DECODE(12, false);
-        else FLACGPU_DECODE(32, false);
-    } else {
-        if (maxord <= 12) FLACGPU_DECODE(12, true);
-        else FLACGPU_DECODE(32, true);
-    }
-#undef FLACGPU_DECODE
 
     if (active) {
         if (status == kFrameOK) {
             // a subframe ends where the next begins; the last one ends at the CRC-16, byte aligned
             const uint32_t end = br.pos();
             if (ch + 1 == C) {
-                const uint32_t want = limit - 16;
                 if (end > limit) status = kFrameTruncated;
-                else if (((end + 7) & ~7u) != want) status = kFrameLength;
+                else if (((end + 7) & ~7u) != limit - 16) status = kFrameLength;
             } else if (end != p.c.subpos[(uint64_t)r * 8 + ch + 1]) {
                 status = end > limit ? kFrameTruncated : kFrameLength;
             }

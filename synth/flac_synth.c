@@ -298,8 +298,8 @@ static int default_precision(int bps, uint32_t bs)
 }
 
 /* Plans the cheapest encoding of one channel signal. */
-static void plan_subframe(const synth_enc_opts *o, const int32_t *sig, uint32_t bs, int bps, sf_plan *pl,
-                          double *win, int32_t *scratch)
+static void plan_subframe(const synth_enc_opts *o, const int32_t *sig, uint32_t bs, int bps, int stream_bps,
+                          sf_plan *pl, double *win, int32_t *scratch)
 {
     sf_head *h = &pl->h;
     memset(h, 0, sizeof *h);
@@ -391,7 +391,7 @@ static void plan_subframe(const synth_enc_opts *o, const int32_t *sig, uint32_t 
                 usable = i + 1;
             }
             if (usable) {
-                int prec = o->qlp_precision ? (int)o->qlp_precision : default_precision(bps, bs);
+                int prec = o->qlp_precision ? (int)o->qlp_precision : default_precision(stream_bps, bs);
                 if (prec > 15) prec = 15;
                 if (prec < 5) prec = 5;
                 uint32_t ord;
@@ -407,6 +407,11 @@ static void plan_subframe(const synth_enc_opts *o, const int32_t *sig, uint32_t 
                     }
                 }
                 if (ord) {
+                    /* subframes of up to 17 bits keep a precision that decodes with 32-bit sums */
+                    if (sb <= 17 && !o->qlp_precision) {
+                        int cap = 32 - sb - ilog2u(ord);
+                        if (prec > cap) prec = cap;
+                    }
                     /* quantise */
                     double cmax = 0;
                     for (uint32_t j = 0; j < ord; j++) { double a = fabs(lp[ord][j]); if (a > cmax) cmax = a; }
@@ -618,7 +623,7 @@ int synth_encode(const int32_t *pcm, uint64_t nsamples, int channels, int bps, u
             int need[4] = {mode < 0 || mode == 0 || mode == 1, mode < 0 || mode == 0 || mode == 2,
                            mode < 0 || mode == 3, mode < 0 || mode == 1 || mode == 2 || mode == 3};
             for (int s = 0; s < 4; s++)
-                if (need[s]) plan_subframe(o, sig[s], bs, bps + (s == 3), &plans[s], win, scratch);
+                if (need[s]) plan_subframe(o, sig[s], bs, bps + (s == 3), bps, &plans[s], win, scratch);
             if (mode < 0) {
                 uint64_t b0 = plans[0].h.bits + plans[1].h.bits, b1 = plans[0].h.bits + plans[3].h.bits;
                 uint64_t b2 = plans[3].h.bits + plans[1].h.bits, b3 = plans[2].h.bits + plans[3].h.bits;
@@ -636,7 +641,7 @@ int synth_encode(const int32_t *pcm, uint64_t nsamples, int channels, int bps, u
         } else {
             for (int c = 0; c < channels; c++) {
                 for (uint32_t i = 0; i < bs; i++) sig[c][i] = src[(size_t)i * (size_t)channels + (size_t)c];
-                plan_subframe(o, sig[c], bs, bps, &plans[c], win, scratch);
+                plan_subframe(o, sig[c], bs, bps, bps, &plans[c], win, scratch);
                 use[c] = &plans[c];
             }
             ch_assign = channels - 1;
