@@ -138,9 +138,10 @@ def main():
     if args.warmup == 0:
         step()
     exp_frames = (nsamples + blocksize - 1) // blocksize
+    check = not os.environ.get("FLAC_BENCH_NOCHECK")   # kernel-ablation experiments produce wrong output on purpose
     bad = [i for i in range(nfiles) if results[i].frames_ok != exp_frames or results[i].samples != nsamples]
-    assert not bad, f"{len(bad)} streams did not decode completely (first: {bad[:4]})"
-    for i in sorted({0, nfiles // 2, nfiles - 1}):
+    assert not (bad and check), f"{len(bad)} streams did not decode completely (first: {bad[:4]})"
+    for i in sorted({0, nfiles // 2, nfiles - 1} if check else ()):
         got = d_out[i * out_stride: i * out_stride + pcm_bytes_per_file].cpu().numpy()
         assert hashlib.md5(got.tobytes()).hexdigest() == infos[i % unique].md5_signature, f"MD5 mismatch, stream {i}"
 

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflacgpu.so")
+LIB_PATH = os.environ.get("FLACGPU_LIB") or os.path.join(_HERE, "lib", "libflacgpu.so")
 
 OK = 0
 FRAME_OK, FRAME_BAD_CRC16, FRAME_BAD_SUBFRAME, FRAME_TRUNCATED, FRAME_LENGTH, FRAME_RANGE, FRAME_UNSUPPORTED, \

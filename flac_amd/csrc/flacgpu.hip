@@ -385,11 +385,11 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
 #define FLACGPU_LAUNCH(MO, W, S) \
         k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C, r.B), st>>>(p)
         if (r.C == 2 && r.B == 2) {
-            FLACGPU_LAUNCH(4, false, true); FLACGPU_LAUNCH(12, false, true); FLACGPU_LAUNCH(32, false, true);
-            FLACGPU_LAUNCH(12, true, true); FLACGPU_LAUNCH(32, true, true);
+            FLACGPU_LAUNCH(12, 0, true); FLACGPU_LAUNCH(32, 0, true); FLACGPU_LAUNCH(12, 1, true);
+            FLACGPU_LAUNCH(32, 1, true); FLACGPU_LAUNCH(12, 2, true); FLACGPU_LAUNCH(32, 2, true);
         } else {
-            FLACGPU_LAUNCH(4, false, false); FLACGPU_LAUNCH(12, false, false); FLACGPU_LAUNCH(32, false, false);
-            FLACGPU_LAUNCH(12, true, false); FLACGPU_LAUNCH(32, true, false);
+            FLACGPU_LAUNCH(12, 0, false); FLACGPU_LAUNCH(32, 0, false); FLACGPU_LAUNCH(12, 1, false);
+            FLACGPU_LAUNCH(32, 1, false); FLACGPU_LAUNCH(12, 2, false); FLACGPU_LAUNCH(32, 2, false);
         }
 #undef FLACGPU_LAUNCH
     }

@@ -30,12 +30,15 @@ namespace flacgpu {
 
 // Every lane walks its own bitstream, so a direct load would touch 64 different
 // cache lines per wave instruction and use 16 bytes of each.  Instead each lane
-// owns a small ring in LDS that the whole wave refills together: four lanes
-// fetch 64 contiguous bytes of one lane's stream (ring_refill), so a wave-wide
-// load reads 16 streams x 64 bytes in whole 64-byte segments.
+// owns a small ring in LDS that the whole wave refills together: two lanes fetch
+// 32 contiguous bytes of one lane's stream (ring_round), so a wave-wide load reads
+// 32 streams x 32 bytes as whole sectors.  A refill is issued one round (8 decode
+// steps) before it is written to the ring, so its latency overlaps decoding.
 constexpr uint32_t kRingWords = 32;   // ring capacity per lane, in 32-bit words
-constexpr uint32_t kUnitWords = 16;   // refill granule: 64 bytes
+constexpr uint32_t kUnitWords = 8;    // refill granule: 32 bytes
+constexpr uint32_t kRoundSteps = 8;   // decode steps (of at most 32 bits) between refill rounds
 constexpr uint32_t kRingBytesPerWave = kRingWords * 64 * 4;
+constexpr uint32_t kNoFill = 0xFFFFFFFFu;
 
 // MSB-first reader over one lane's bitstream.  Positions are bits from the
 // 64-byte-aligned address at or before the frame's first byte.  Ring word w of
@@ -49,15 +52,17 @@ struct BitReader {
     uint32_t nwords;         // words readable from gbase
     uint32_t *ring;
     uint64_t gvec;           // vector (16-byte) index of gbase in the input buffer
-    uint32_t rd;             // next word to fetch into `nx`
+    uint32_t rd;             // index of the word held in `pf`
     uint32_t fill;
-    uint32_t bit;            // bits of `hi` already consumed
-    uint32_t hi, lo, nx;     // words rd-3, rd-2, rd-1
+    uint32_t issued;         // value of `fill` when a refill was last issued and not yet written, or kNoFill
+    uint32_t bit;            // bits of `hi` already consumed (0..31)
+    uint32_t hi, lo, pf;     // words rd-2, rd-1, rd
 
+    __device__ inline uint32_t gload(uint32_t w) const { return w < nwords ? __builtin_bswap32(gbase[w]) : 0u; }
     __device__ inline uint32_t fetch(uint32_t w) const
     {
         if (w < fill) return ring[(w & (kRingWords - 1)) * 64];
-        return w < nwords ? __builtin_bswap32(gbase[w]) : 0u;
+        return gload(w);
     }
     __device__ inline void init(const uint8_t *in, uint64_t in_vecs, uint64_t goff, uint32_t *lane_ring)
     {
@@ -66,35 +71,49 @@ struct BitReader {
         gvec = b >> 4;
         nwords = (uint32_t)min((in_vecs - gvec) * 4, (uint64_t)0xFFFFFFFFu);
         ring = lane_ring;
-        rd = fill = bit = hi = lo = nx = 0;
+        rd = fill = bit = hi = lo = pf = 0;
+        issued = kNoFill;
     }
     __device__ inline void null(uint32_t *lane_ring)
     {
         gbase = nullptr; nwords = 0; ring = lane_ring; gvec = 0;
-        rd = fill = bit = hi = lo = nx = 0;
-    }
-    __device__ inline void advance()
-    {
-        hi = lo; lo = nx; nx = fetch(rd); ++rd;
+        rd = fill = bit = hi = lo = pf = 0;
+        issued = kNoFill;
     }
     __device__ inline void seek(uint32_t bitpos)
     {
         const uint32_t w = bitpos >> 5;
         bit = bitpos & 31;
-        fill = w & ~(kUnitWords - 1);   // ring restarts at this unit; until the next refill, words come from global memory
-        rd = w;
-        hi = fetch(rd); lo = fetch(rd + 1); nx = fetch(rd + 2);
-        rd += 3;
+        fill = w & ~(kUnitWords - 1);   // ring restarts at this unit; until it is refilled, words come from global memory
+        issued = kNoFill;
+        hi = gload(w); lo = gload(w + 1); pf = gload(w + 2);
+        rd = w + 2;
     }
-    __device__ inline uint32_t pos() const { return (rd - 3) * 32 + bit; }
+    __device__ inline uint32_t pos() const { return (rd - 2) * 32 + bit; }
     __device__ inline uint32_t peek() const
     {
         return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (32 - bit));
     }
-    __device__ inline void skip(uint32_t n)   // n <= 32
+    // General skip (n <= 32): checks that the ring holds the word it moves to.
+    __device__ inline void skip(uint32_t n)
     {
         bit += n;
-        if (bit >= 32) { bit -= 32; advance(); }
+        if (bit >= 32) { bit -= 32; hi = lo; lo = pf; ++rd; pf = fetch(rd); }
+    }
+    // Skip (n <= 32) for the unrolled Rice loop: selects instead of branches, and the ring
+    // read is issued every step and consumed no earlier than the next one.  ring_refill
+    // keeps the ring ahead for 16 steps of at most 32 bits; beyond that the word comes
+    // from global memory.
+    __device__ inline void skip_fast(uint32_t n)
+    {
+        bit += n;
+        const bool take = bit >= 32;
+        hi = take ? lo : hi;
+        lo = take ? pf : lo;
+        rd += take ? 1u : 0u;
+        bit &= 31;
+        pf = ring[(rd & (kRingWords - 1)) * 64];
+        if (__builtin_expect(rd >= fill, 0)) pf = gload(rd);   // the lane outran its ring (codes longer than 32 bits)
     }
     __device__ inline void skip_long(uint32_t n) { seek(pos() + n); }
     __device__ inline uint32_t read(uint32_t n)   // n <= 32
@@ -111,43 +130,61 @@ struct BitReader {
     }
 };
 
-// Wave-wide refill: every lane whose ring holds 16 or fewer unread words gets its
-// next 64 bytes.  Lane 4i+p fetches vector p of lane i's unit, for four groups of 16
-// lanes in turn.  Must be called by all 64 lanes together.  After the call a
-// participating lane has more than 16 unread words, enough for 16 steps of at most
-// 32 bits each.
-__device__ inline void ring_refill(BitReader &br, bool active, const uint4 *in_vec, uint64_t in_vecs,
-                                   uint32_t *wave_ring, uint32_t lane)
+// What a lane holds, as a helper, between two refill rounds: the vectors it loaded for
+// other lanes' rings and the ring position they belong to.
+struct RingFetch {
+    uint4 v[2];
+    uint32_t at[2];   // target's `fill` when the load was issued, or kNoFill
+    __device__ inline void clear() { at[0] = at[1] = kNoFill; v[0] = v[1] = uint4{0u, 0u, 0u, 0u}; }
+};
+
+// One refill round; all 64 lanes call it together, every kRoundSteps decode steps.
+//   1. commit: the vectors loaded in the previous round are written to their owners'
+//      rings (unless the owner has repositioned its reader since);
+//   2. issue: every lane with 16 or fewer unread words asks for its next 32 bytes; lane
+//      2i+p loads vector p of lane i's unit (two half-wave passes), to be committed in
+//      the next round.
+// A lane that starts a round with at least 9 unread words has at least 9 at the next
+// round too, whatever it consumes in between (at most 8 words), so the decode loops
+// never wait for memory.  After repositioning, three rounds in a row restore the margin.
+__device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active, const uint4 *in_vec, uint64_t in_vecs,
+                                  uint32_t *wave_ring, uint32_t lane)
 {
-    if (active && (int32_t)(br.fill - br.rd) < -(int32_t)kUnitWords + 1) br.fill = br.rd & ~(kUnitWords - 1);
-    const bool need = active && (int32_t)(br.fill - br.rd) <= (int32_t)kUnitWords;
-    const uint64_t need_mask = __ballot(need);
-    if (need_mask == 0) return;
-    const uint64_t gv = br.gvec + (br.fill >> 2);
-    const uint32_t info = (br.fill & (kRingWords - 1)) | (need ? 0x80000000u : 0u);
-    const uint32_t p = lane & 3;
+    const uint32_t p = lane & 1;
     __builtin_amdgcn_wave_barrier();
+    // ---- commit
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (((need_mask >> (16 * g)) & 0xFFFF) == 0) continue;
-        const uint32_t t = 16 * g + (lane >> 2);
-        const uint32_t t_info = (uint32_t)__shfl((int)info, (int)t);
-        const uint64_t t_gv = ((uint64_t)(uint32_t)__shfl((int)(gv >> 32), (int)t) << 32) |
-                              (uint32_t)__shfl((int)(uint32_t)gv, (int)t);
-        if (t_info & 0x80000000u) {
-            const uint64_t v_idx = t_gv + p;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (v_idx < in_vecs) v = in_vec[v_idx];
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t t = 32 * s + (lane >> 1);
+        const uint32_t t_fill = (uint32_t)__shfl((int)br.fill, (int)t);
+        if (rf.at[s] != kNoFill && rf.at[s] == t_fill) {
             uint32_t *dst = wave_ring + t;
-            const uint32_t slot = (t_info + 4 * p) & (kRingWords - 1);
-            dst[(slot + 0) * 64] = __builtin_bswap32(v.x);
-            dst[(slot + 1) * 64] = __builtin_bswap32(v.y);
-            dst[(slot + 2) * 64] = __builtin_bswap32(v.z);
-            dst[(slot + 3) * 64] = __builtin_bswap32(v.w);
+            const uint32_t slot = (t_fill + 4 * p) & (kRingWords - 1);
+            dst[(slot + 0) * 64] = __builtin_bswap32(rf.v[s].x);
+            dst[(slot + 1) * 64] = __builtin_bswap32(rf.v[s].y);
+            dst[(slot + 2) * 64] = __builtin_bswap32(rf.v[s].z);
+            dst[(slot + 3) * 64] = __builtin_bswap32(rf.v[s].w);
         }
     }
+    if (br.issued != kNoFill && br.issued == br.fill) br.fill += kUnitWords;
+    br.issued = kNoFill;
     __builtin_amdgcn_wave_barrier();
-    if (need) br.fill += kUnitWords;
+    // ---- issue
+    if (active && (int32_t)(br.fill - br.rd) < -(int32_t)kUnitWords + 1) br.fill = br.rd & ~(kUnitWords - 1);
+    const bool want = active && (int32_t)(br.fill - br.rd) <= 16;
+    const uint64_t gv = br.gvec + (br.fill >> 2);
+    const uint32_t tag = want ? br.fill : kNoFill;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t t = 32 * s + (lane >> 1);
+        rf.at[s] = (uint32_t)__shfl((int)tag, (int)t);
+        const uint64_t t_gv = ((uint64_t)(uint32_t)__shfl((int)(gv >> 32), (int)t) << 32) |
+                              (uint32_t)__shfl((int)(uint32_t)gv, (int)t);
+        const uint64_t v_idx = t_gv + p;
+        rf.v[s] = uint4{0u, 0u, 0u, 0u};
+        if (rf.at[s] != kNoFill && v_idx < in_vecs) rf.v[s] = in_vec[v_idx];
+    }
+    if (want) br.issued = br.fill;
 }
 
 // Unary-coded count: zeros up to and including the terminating one are consumed.
@@ -164,23 +201,28 @@ __device__ inline uint32_t read_unary(BitReader &br, uint32_t limit)
     return q + z;
 }
 
+// a * b + c on the low 24 bits of a and b (sign-extended), low 32 bits of the result: one full-rate
+// instruction where a 32-bit multiply takes four.  Exact whenever a and b fit 24 bits.  Written as
+// asm because the compiler only selects it when it can see both sign-extensions in the same block.
+__device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
+{
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ inline int32_t unzigzag(uint32_t u) { return (int32_t)((u >> 1) ^ (0u - (u & 1))); }
 
-// One Rice code with parameter k (0..30).
+// One Rice code with parameter k (0..30), general form.
 __device__ inline int32_t read_rice(BitReader &br, uint32_t k, uint32_t limit)
 {
     const uint32_t w = br.peek();
     uint32_t q, low;
-    if (w != 0) {
-        q = __clz(w);
-        const uint32_t n = q + 1 + k;
-        if (n <= 32) {
-            low = __builtin_amdgcn_ubfe(w, 32 - n, k);
-            br.skip(n);
-        } else {
-            br.skip(q + 1);
-            low = br.read(k);
-        }
+    const uint32_t n = __clz(w) + 1 + k;   // clz(0) = 32, so n > 32 when the window is all zeros
+    if (n <= 32) {
+        q = n - 1 - k;
+        low = __builtin_amdgcn_ubfe(w, 32 - n, k);
+        br.skip(n);
     } else {
         q = read_unary(br, limit);
         low = br.read(k);
@@ -188,15 +230,29 @@ __device__ inline int32_t read_rice(BitReader &br, uint32_t k, uint32_t limit)
     return unzigzag((q << k) | low);
 }
 
+// One Rice code inside the unrolled loop: no branch unless the code is longer than 32 bits.
+__device__ inline int32_t read_rice_fast(BitReader &br, uint32_t k, uint32_t limit)
+{
+    const uint32_t w = br.peek();
+    uint32_t q = __clz(w);
+    const uint32_t n = q + 1 + k;
+    uint32_t low;
+    if (__builtin_expect(n > 32, 0)) {
+        q = read_unary(br, limit);
+        low = br.read(k);
+    } else {
+        low = __builtin_amdgcn_ubfe(w, 32 - n, k);
+        br.skip_fast(n);
+    }
+    return unzigzag((q << k) | low);
+}
+
 // Length-only version for the skim pass.
 __device__ inline void skip_rice(BitReader &br, uint32_t k, uint32_t limit)
 {
-    const uint32_t w = br.peek();
-    if (w != 0) {
-        const uint32_t n = __clz(w) + 1 + k;
-        if (n <= 32) br.skip(n);
-        else { br.skip(n - k); br.skip(k); }
-    } else {
+    const uint32_t n = __clz(br.peek()) + 1 + k;
+    if (n <= 32) br.skip(n);
+    else {
         (void)read_unary(br, limit);
         br.skip(k);
     }
@@ -274,9 +330,13 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
     int rc = kFrameOK;
     const uint4 *in_vec = reinterpret_cast<const uint4 *>(in);
 
+    RingFetch rf;
+    rf.clear();
+    ring_round(br, rf, state != S_DONE, in_vec, in_vecs, wave_ring, lane);
+    ring_round(br, rf, state != S_DONE, in_vec, in_vecs, wave_ring, lane);
     while (__any(state != S_DONE)) {
-        ring_refill(br, state != S_DONE, in_vec, in_vecs, wave_ring, lane);
-        for (int step = 0; step < 16; ++step) {
+        ring_round(br, rf, state != S_DONE, in_vec, in_vecs, wave_ring, lane);
+        for (int step = 0; step < (int)kRoundSteps; ++step) {
             if (state == S_RICE) {
                 skip_rice(br, k, limit);
                 if (--part_rem == 0) state = S_PART;
@@ -363,7 +423,6 @@ __device__ inline uint32_t wave_max_u32(uint32_t v)
 
 // Predictor classes: a wave runs in the smallest class that holds the largest
 // order among its lanes.  U = history ring size and unroll factor, NT = taps.
-__device__ inline int order_class(uint32_t maxord) { return maxord <= 4 ? 4 : maxord <= 12 ? 12 : 32; }
 __host__ __device__ constexpr int class_unroll(int nt) { return nt <= 16 ? 16 : 32; }
 
 constexpr uint32_t kTile = 32;   // samples staged in LDS between write-outs
@@ -377,7 +436,9 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C, uint32_t B)
 }
 
 // One lane per (frame, channel); a wave holds floor(64 / C) frames.
-// NT: predictor taps evaluated per sample (4, 12 or 32).  WIDE: 64-bit sums.
+// NT: predictor taps evaluated per sample (12 or 32).
+// ARITH: 0 = 24-bit multiplies (every subframe of the wave is at most 24 bits wide),
+//        1 = 32-bit multiplies, 2 = 64-bit sums.
 // STEREO16: C == 2 and B == 2, the pair of lanes writes one packed word per sample.
 //
 // Samples are processed in groups of U.  A group in which every lane is in the
@@ -386,7 +447,7 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C, uint32_t B)
 // moved.  Any other group (warm-up samples, coefficient parsing, partition
 // boundary inside the group, escape-coded or verbatim data, the tail of a block)
 // runs the generic rolled body with a shift-register history.
-template <int NT, bool WIDE, bool STEREO16>
+template <int NT, int ARITH, bool STEREO16>
 __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -439,9 +500,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     }
     const uint32_t maxord = wave_max_u32(active && status == kFrameOK ? h.order : 0);
     const bool any_wide = __any(need_wide);
-    // a wave is decoded by exactly one instantiation: narrow 4 / 12 / 32 taps, wide 12 / 32 taps
-    const int cls = any_wide ? (maxord <= 12 ? 12 : 32) : order_class(maxord);
-    if (cls != NT || any_wide != WIDE) return;
+    const bool any_big = __any(active && status == kFrameOK && h.sbps > 24);
+    // a wave is decoded by exactly one instantiation: 12 or 32 taps x {24-bit, 32-bit, 64-bit} arithmetic
+    const int cls = maxord <= 12 ? 12 : 32;
+    const int arith = any_wide ? 2 : any_big ? 1 : 0;
+    if (cls != NT || arith != ARITH) return;
 
     const uint32_t bs_max = wave_max_u32(active ? bs : 0);
     if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; }
@@ -507,31 +570,36 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
         }
     };
     // Stereo decorrelation + staging of one sample into the LDS tile.  `col` = sample index inside the tile.
+    // Samples that do not fit the subframe's width mark the frame invalid (ovf).
+    const uint32_t sbits = h.sbps ? h.sbps : 32u;
+    const bool is_ls = ca == 8, is_sr = ca == 9, is_ms = ca == 10;
+    uint32_t ovf = 0;
     auto emit = [&](int32_t v, bool live, uint32_t col) {
+        ovf |= (uint32_t)(v ^ __builtin_amdgcn_sbfe(v, 0, sbits));
         uint32_t o = (uint32_t)v << h.wasted;
         if (STEREO16) {
-            const uint32_t q = (uint32_t)__shfl_xor((int)o, 1);
+            // exchange with the other lane of the pair (quad_perm [1,0,3,2])
+            const uint32_t q = (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
             const uint32_t a = ch == 0 ? o : q, b = ch == 0 ? q : o;   // channel 0 / channel 1 as coded
-            uint32_t L = a, R = b;
-            if (ca == 8) R = a - b;
-            else if (ca == 9) L = a + b;
-            else if (ca == 10) {
-                const uint32_t mm = (a << 1) | (b & 1);
-                L = (uint32_t)((int32_t)(mm + b) >> 1);
-                R = (uint32_t)((int32_t)(mm - b) >> 1);
-            }
+            const uint32_t mm = (a << 1) | (b & 1);
+            const uint32_t mL = (uint32_t)((int32_t)(mm + b) >> 1), mR = (uint32_t)((int32_t)(mm - b) >> 1);
+            const uint32_t L = is_ms ? mL : is_sr ? a + b : a;
+            const uint32_t R = is_ms ? mR : is_ls ? a - b : b;
+#ifdef ABLATE_TILE
+            if (live && ch == 0 && L == 0x12345u)
+#else
             if (live && ch == 0)
+#endif
                 *reinterpret_cast<uint32_t *>(tile + fl * row_stride + col * 4) = (L & 0xFFFFu) | (R << 16);
         } else {
             if (C == 2) {
-                const uint32_t q = (uint32_t)__shfl_xor((int)o, 1);
-                if (ca == 8) { if (ch == 1) o = q - o; }
-                else if (ca == 9) { if (ch == 0) o = o + q; }
-                else if (ca == 10) {
-                    const uint32_t m = ch == 0 ? o : q, s = ch == 0 ? q : o;
-                    const uint32_t mm = (m << 1) | (s & 1);
-                    o = ch == 0 ? (uint32_t)((int32_t)(mm + s) >> 1) : (uint32_t)((int32_t)(mm - s) >> 1);
-                }
+                const uint32_t q = (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
+                const uint32_t a = ch == 0 ? o : q, b = ch == 0 ? q : o;
+                const uint32_t mm = (a << 1) | (b & 1);
+                const uint32_t mL = (uint32_t)((int32_t)(mm + b) >> 1), mR = (uint32_t)((int32_t)(mm - b) >> 1);
+                const uint32_t L = is_ms ? mL : is_sr ? a + b : a;
+                const uint32_t R = is_ms ? mR : is_ls ? a - b : b;
+                o = ch == 0 ? L : R;
             }
             if (live) {
                 uint8_t *t = tile + fl * row_stride + (col * C + ch) * B;
@@ -540,6 +608,25 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 else if (B == 3) { t[0] = (uint8_t)o; t[1] = (uint8_t)(o >> 8); t[2] = (uint8_t)(o >> 16); }
                 else t[0] = (uint8_t)o;
             }
+        }
+    };
+    // Sum of coef[j] * x[j] over the NT taps in the wave's arithmetic class, shifted.
+    auto predict = [&](auto tap) -> int32_t {
+        if (ARITH == 2) {
+            int64_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) sum += (int64_t)coef[j] * (int64_t)tap(j);
+            return wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum) >> shift;
+        } else if (ARITH == 1) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) sum += (uint32_t)coef[j] * (uint32_t)tap(j);
+            return (int32_t)sum >> shift;
+        } else {
+            int32_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) sum = mad_i24(coef[j], tap(j), sum);
+            return sum >> shift;
         }
     };
     // Writes the staged samples [n0, n0 + kTile) of every frame of this wave as runs of up to kTile*C*B bytes.
@@ -552,7 +639,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 const uint32_t f = i / row_words, col = i - f * row_words;
                 const uint32_t fbs = s_bs[f];
                 const uint32_t valid = fbs > n0 ? min(kTile, fbs - n0) * CB : 0;
+#ifdef ABLATE_STORE
+                if (col * 4 < valid && fbs == 0xFFFFFFFu)
+#else
                 if (col * 4 < valid)
+#endif
                     *reinterpret_cast<uint32_t *>(s_dst[f] + (uint64_t)n0 * CB + col * 4) =
                         *reinterpret_cast<const uint32_t *>(tile + f * row_stride + col * 4);
             }
@@ -569,12 +660,16 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 
     // One extra group runs past the end of the block when some lane's subframe is all warm-up
     // samples: its predictor parameters still have to be consumed.
-    ring_refill(br, active && status == kFrameOK, reinterpret_cast<const uint4 *>(p.in), p.in_vecs, wave_ring, lane);
+    const uint4 *in_vec = reinterpret_cast<const uint4 *>(p.in);
+    RingFetch rf;
+    rf.clear();
+    ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
+    ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
     const bool trailing = __any(active && status == kFrameOK && kind == 2 && order >= bs);
     const uint32_t n_end = ((bs_max + U - 1) / U) * U + (trailing ? U : 0);
     for (uint32_t n0 = 0; n0 < n_end; n0 += U) {
         const uint32_t tile_n0 = n0 & ~(kTile - 1);
-        ring_refill(br, active && status == kFrameOK, reinterpret_cast<const uint4 *>(p.in), p.in_vecs, wave_ring, lane);
+        ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
         const bool on = active && status == kFrameOK && n0 < bs;
         if (on && kind == 2 && started && part_rem == 0) next_partition();
         if (on && br.pos() > limit) status = kFrameTruncated;
@@ -587,21 +682,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             // ---- fast group: U Rice codes per lane, history renamed -------------------------
 #pragma unroll
             for (int P = 0; P < U; ++P) {
+                if (P && P % kRoundSteps == 0) ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
                 int32_t v = constval;
-                if (rice_on) v = read_rice(br, k, limit);
-                int32_t pred;
-                if (WIDE) {
-                    int64_t sum = 0;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) sum += (int64_t)coef[j] * (int64_t)ring[(P + U - 1 - j) % U];
-                    pred = wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum) >> shift;
-                } else {
-                    uint32_t sum = 0;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) sum += (uint32_t)coef[j] * (uint32_t)ring[(P + U - 1 - j) % U];
-                    pred = (int32_t)sum >> shift;
-                }
-                if (rice_on) v = (int32_t)((uint32_t)v + (uint32_t)pred);
+                if (rice_on) v = read_rice_fast(br, k, limit);
+                const int32_t pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
+                v = rice_on ? (int32_t)((uint32_t)v + (uint32_t)pred) : v;
                 ring[P] = v;
                 emit(v, on, n0 + P - tile_n0);
             }
@@ -612,6 +697,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 #pragma unroll
             for (int j = 0; j < NT; ++j) hist[j] = ring[U - 1 - j];
             for (uint32_t n = n0; n < n0 + U; ++n) {
+                if (n != n0 && ((n - n0) % kRoundSteps) == 0)
+                    ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
                 const bool ok = active && status == kFrameOK;
                 const bool live = ok && n < bs;
                 if (ok && kind == 2 && !started && n >= order) {
@@ -636,18 +723,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                         }
                     }
                 }
-                int32_t pred;
-                if (WIDE) {
-                    int64_t sum = 0;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) sum += (int64_t)coef[j] * (int64_t)hist[j];
-                    pred = wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum) >> shift;
-                } else {
-                    uint32_t sum = 0;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) sum += (uint32_t)coef[j] * (uint32_t)hist[j];
-                    pred = (int32_t)sum >> shift;
-                }
+                const int32_t pred = predict([&](int j) { return hist[j]; });
                 if (predicted) v = (int32_t)((uint32_t)v + (uint32_t)pred);
 #pragma unroll
                 for (int j = NT - 1; j > 0; --j) hist[j] = hist[j - 1];
@@ -662,6 +738,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     }
 
     if (active) {
+        if (status == kFrameOK && ovf && sbits < 32) status = kFrameBadSubframe;   // a sample wider than its subframe
         if (status == kFrameOK) {
             // a subframe ends where the next begins; the last one ends at the CRC-16, byte aligned
             const uint32_t end = br.pos();

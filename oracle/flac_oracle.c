@@ -431,6 +431,11 @@ static int decode_subframe(br_t *b, int32_t *s, uint32_t bs, int bps)
         return ORC_FRAME_BAD_SUBFRAME;
     }
     if (b->err) return ORC_FRAME_TRUNCATED;
+    /* RFC 9639: a decoded sample must fit the subframe's bit depth; a stream where it does not is invalid */
+    if (bps < 32) {
+        const int32_t lo = -(int32_t)(1u << (bps - 1)), hi = (int32_t)((1u << (bps - 1)) - 1);
+        for (uint32_t i = 0; i < bs; i++) if (s[i] < lo || s[i] > hi) return ORC_FRAME_BAD_SUBFRAME;
+    }
     if (wasted) {
         uint32_t *u = (uint32_t *)s;
         for (uint32_t i = 0; i < bs; i++) u[i] <<= wasted;
