@@ -22,6 +22,8 @@
 // exceeds 32, which accumulate in 64 bits.
 #pragma once
 
+#include <type_traits>
+
 #include "device_types.hpp"
 
 namespace flacgpu {
@@ -46,7 +48,8 @@ constexpr uint32_t kNoFill = 0xFFFFFFFFu;
 // lane's column), stored big-endian-corrected; the ring holds words
 // [fill - kRingWords, fill).  A word the ring does not hold is read from global
 // memory directly (after a seek, or when a lane outruns the refill schedule).
-// Words past the end of the input buffer read as zero.
+// Reads never go past the end of the input buffer (a lane that runs off the end of the
+// batch sees zeros or a repeat of the last 16 bytes, and stops at its frame's bit limit).
 struct BitReader {
     const uint32_t *gbase;   // global words from the aligned base
     uint32_t nwords;         // words readable from gbase
@@ -58,7 +61,18 @@ struct BitReader {
     uint32_t bit;            // bits of `hi` already consumed (0..31)
     uint32_t hi, lo, pf;     // words rd-2, rd-1, rd
 
-    __device__ inline uint32_t gload(uint32_t w) const { return w < nwords ? __builtin_bswap32(gbase[w]) : 0u; }
+    // Direct read of stream word w.  Only cold paths use it (a repositioned reader, a lane that outran
+    // its ring).  The load and its wait are one asm statement on purpose: a compiler-visible load in a
+    // rarely taken branch makes hipcc wait for ALL outstanding memory operations wherever the paths
+    // join, i.e. once per sample in the hot loop, which would serialise the refill prefetches.
+    __device__ inline uint32_t gload(uint32_t w) const
+    {
+        if (w >= nwords) return 0u;
+        uint32_t v;
+        const uint32_t *p = gbase + w;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return __builtin_bswap32(v);
+    }
     __device__ inline uint32_t fetch(uint32_t w) const
     {
         if (w < fill) return ring[(w & (kRingWords - 1)) * 64];
@@ -99,21 +113,6 @@ struct BitReader {
     {
         bit += n;
         if (bit >= 32) { bit -= 32; hi = lo; lo = pf; ++rd; pf = fetch(rd); }
-    }
-    // Skip (n <= 32) for the unrolled Rice loop: selects instead of branches, and the ring
-    // read is issued every step and consumed no earlier than the next one.  ring_refill
-    // keeps the ring ahead for 16 steps of at most 32 bits; beyond that the word comes
-    // from global memory.
-    __device__ inline void skip_fast(uint32_t n)
-    {
-        bit += n;
-        const bool take = bit >= 32;
-        hi = take ? lo : hi;
-        lo = take ? pf : lo;
-        rd += take ? 1u : 0u;
-        bit &= 31;
-        pf = ring[(rd & (kRingWords - 1)) * 64];
-        if (__builtin_expect(rd >= fill, 0)) pf = gload(rd);   // the lane outran its ring (codes longer than 32 bits)
     }
     __device__ inline void skip_long(uint32_t n) { seek(pos() + n); }
     __device__ inline uint32_t read(uint32_t n)   // n <= 32
@@ -180,9 +179,11 @@ __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active, con
         rf.at[s] = (uint32_t)__shfl((int)tag, (int)t);
         const uint64_t t_gv = ((uint64_t)(uint32_t)__shfl((int)(gv >> 32), (int)t) << 32) |
                               (uint32_t)__shfl((int)(uint32_t)gv, (int)t);
-        const uint64_t v_idx = t_gv + p;
-        rf.v[s] = uint4{0u, 0u, 0u, 0u};
-        if (rf.at[s] != kNoFill && v_idx < in_vecs) rf.v[s] = in_vec[v_idx];
+        // the load is unconditional (a lane with nothing to fetch re-reads vector 0): a branch around
+        // it would make the compiler copy the result, and so wait for it, right here
+        uint64_t v_idx = t_gv + p;
+        v_idx = rf.at[s] == kNoFill ? 0 : (v_idx < in_vecs ? v_idx : in_vecs - 1);   // never past the input
+        rf.v[s] = in_vec[v_idx];
     }
     if (want) br.issued = br.fill;
 }
@@ -226,23 +227,6 @@ __device__ inline int32_t read_rice(BitReader &br, uint32_t k, uint32_t limit)
     } else {
         q = read_unary(br, limit);
         low = br.read(k);
-    }
-    return unzigzag((q << k) | low);
-}
-
-// One Rice code inside the unrolled loop: no branch unless the code is longer than 32 bits.
-__device__ inline int32_t read_rice_fast(BitReader &br, uint32_t k, uint32_t limit)
-{
-    const uint32_t w = br.peek();
-    uint32_t q = __clz(w);
-    const uint32_t n = q + 1 + k;
-    uint32_t low;
-    if (__builtin_expect(n > 32, 0)) {
-        q = read_unary(br, limit);
-        low = br.read(k);
-    } else {
-        low = __builtin_amdgcn_ubfe(w, 32 - n, k);
-        br.skip_fast(n);
     }
     return unzigzag((q << k) | low);
 }
@@ -574,7 +558,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     const uint32_t sbits = h.sbps ? h.sbps : 32u;
     const bool is_ls = ca == 8, is_sr = ca == 9, is_ms = ca == 10;
     uint32_t ovf = 0;
-    auto emit = [&](int32_t v, bool live, uint32_t col) {
+    auto emit = [&](int32_t v, bool live, uint32_t col, auto always) {
+        constexpr bool ALWAYS = decltype(always)::value;   // fast groups store from every lane: a dead lane's row is never written out
         ovf |= (uint32_t)(v ^ __builtin_amdgcn_sbfe(v, 0, sbits));
         uint32_t o = (uint32_t)v << h.wasted;
         if (STEREO16) {
@@ -585,11 +570,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             const uint32_t mL = (uint32_t)((int32_t)(mm + b) >> 1), mR = (uint32_t)((int32_t)(mm - b) >> 1);
             const uint32_t L = is_ms ? mL : is_sr ? a + b : a;
             const uint32_t R = is_ms ? mR : is_ls ? a - b : b;
-#ifdef ABLATE_TILE
-            if (live && ch == 0 && L == 0x12345u)
-#else
-            if (live && ch == 0)
-#endif
+            if (ALWAYS || (live && ch == 0))   // both lanes of a pair hold the same word
                 *reinterpret_cast<uint32_t *>(tile + fl * row_stride + col * 4) = (L & 0xFFFFu) | (R << 16);
         } else {
             if (C == 2) {
@@ -601,7 +582,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 const uint32_t R = is_ms ? mR : is_ls ? a - b : b;
                 o = ch == 0 ? L : R;
             }
-            if (live) {
+            if ((ALWAYS && fl < F) || live) {   // lanes past the last whole frame of the wave own no tile row
                 uint8_t *t = tile + fl * row_stride + (col * C + ch) * B;
                 if (B == 2) *reinterpret_cast<uint16_t *>(t) = (uint16_t)o;
                 else if (B == 4) *reinterpret_cast<uint32_t *>(t) = o;
@@ -610,22 +591,38 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             }
         }
     };
-    // Sum of coef[j] * x[j] over the NT taps in the wave's arithmetic class, shifted.
+    // Sum of coef[j] * x[j] over the NT taps in the wave's arithmetic class, shifted.  The taps are
+    // summed in three independent chains and the most recent sample (tap 0) is added last: a dependent
+    // vector instruction waits about ten cycles for its operand, and tap 0 is the only one that depends
+    // on the previous sample's result.
     auto predict = [&](auto tap) -> int32_t {
         if (ARITH == 2) {
-            int64_t sum = 0;
+            int64_t s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) sum += (int64_t)coef[j] * (int64_t)tap(j);
+            for (int j = 1; j < NT; ++j) {
+                const int64_t m = (int64_t)coef[j] * (int64_t)tap(j);
+                if (j % 3 == 1) s0 += m; else if (j % 3 == 2) s1 += m; else s2 += m;
+            }
+            const int64_t sum = (s0 + s1) + s2 + (int64_t)coef[0] * (int64_t)tap(0);
             return wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum) >> shift;
         } else if (ARITH == 1) {
-            uint32_t sum = 0;
+            uint32_t s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) sum += (uint32_t)coef[j] * (uint32_t)tap(j);
+            for (int j = 1; j < NT; ++j) {
+                const uint32_t m = (uint32_t)coef[j] * (uint32_t)tap(j);
+                if (j % 3 == 1) s0 += m; else if (j % 3 == 2) s1 += m; else s2 += m;
+            }
+            const uint32_t sum = (s0 + s1) + s2 + (uint32_t)coef[0] * (uint32_t)tap(0);
             return (int32_t)sum >> shift;
         } else {
-            int32_t sum = 0;
+            int32_t s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) sum = mad_i24(coef[j], tap(j), sum);
+            for (int j = 1; j < NT; ++j) {
+                if (j % 3 == 1) s0 = mad_i24(coef[j], tap(j), s0);
+                else if (j % 3 == 2) s1 = mad_i24(coef[j], tap(j), s1);
+                else s2 = mad_i24(coef[j], tap(j), s2);
+            }
+            const int32_t sum = mad_i24(coef[0], tap(0), (s0 + s1) + s2);
             return sum >> shift;
         }
     };
@@ -639,11 +636,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 const uint32_t f = i / row_words, col = i - f * row_words;
                 const uint32_t fbs = s_bs[f];
                 const uint32_t valid = fbs > n0 ? min(kTile, fbs - n0) * CB : 0;
-#ifdef ABLATE_STORE
-                if (col * 4 < valid && fbs == 0xFFFFFFFu)
-#else
                 if (col * 4 < valid)
-#endif
                     *reinterpret_cast<uint32_t *>(s_dst[f] + (uint64_t)n0 * CB + col * 4) =
                         *reinterpret_cast<const uint32_t *>(tile + f * row_stride + col * 4);
             }
@@ -678,20 +671,70 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
         const bool simple = unstarted ? false
                                       : (!on || kind == 0 ||
                                          (rice_on && !escaped && part_rem >= (uint32_t)U && n0 + U <= bs));
-        if (__all(simple)) {
-            // ---- fast group: U Rice codes per lane, history renamed -------------------------
+        bool redo = true;            // lanes the generic body below has to process
+#ifdef FLACGPU_DEBUG_NO_FAST
+        bool run_generic = true;
+#else
+        bool run_generic = !__all(simple);
+#endif
+        if (!run_generic) {
+            // ---- fast group: U Rice codes per lane, speculatively and without branches ------
+            // Every code is assumed to fit the 32-bit window and every word to be in the ring.
+            // A lane for which that fails (longest code seen > 32 bits, or the reader ran past
+            // `fill`) has produced garbage: its state is rolled back to the start of the group
+            // and the generic body redoes the group for it.
+            const uint32_t s_rd = br.rd, s_bit = br.bit, s_hi = br.hi, s_lo = br.lo, s_pf = br.pf, s_ovf = ovf;
+            int32_t s_hist[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) s_hist[j] = ring[U - 1 - j];
+            uint32_t longest = 0;
+            bool starved = false;
 #pragma unroll
             for (int P = 0; P < U; ++P) {
-                if (P && P % kRoundSteps == 0) ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
-                int32_t v = constval;
-                if (rice_on) v = read_rice_fast(br, k, limit);
+                if (P && P % kRoundSteps == 0) {
+                    starved = starved || (rice_on && br.rd >= br.fill);
+                    ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
+                }
+                // Rice code: unary part = leading zeros of the window, then k low bits
+                const uint32_t w = br.peek();
+                const uint32_t q = __clz(w);
+                const uint32_t nb = q + 1 + k;
+                longest = max(longest, nb);
+                const uint32_t low = __builtin_amdgcn_ubfe(w, 32 - nb, k);
+                const int32_t res = unzigzag((q << k) | low);
+                br.bit += rice_on ? nb : 0u;
+                const bool take = br.bit >= 32;
+                br.hi = take ? br.lo : br.hi;
+                br.lo = take ? br.pf : br.lo;
+                br.rd += take ? 1u : 0u;
+                br.bit &= 31;
+                br.pf = br.ring[(br.rd & (kRingWords - 1)) * 64];
                 const int32_t pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
-                v = rice_on ? (int32_t)((uint32_t)v + (uint32_t)pred) : v;
+                const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
                 ring[P] = v;
-                emit(v, on, n0 + P - tile_n0);
+                emit(v, on, n0 + P - tile_n0, std::true_type{});
             }
-            if (rice_on) part_rem -= U;
-        } else {
+            starved = starved || (rice_on && br.rd >= br.fill);
+#ifdef FLACGPU_DEBUG_FORCE_REDO
+            redo = rice_on;
+#else
+            redo = rice_on && (starved || longest > 32);
+#endif
+            // the two lanes of a stereo pair exchange samples: they are redone together
+            if (C == 2) redo = redo || __builtin_amdgcn_mov_dpp((int)redo, 0xB1, 0xF, 0xF, true) != 0;
+            if (rice_on && !redo) part_rem -= U;
+            run_generic = __any(redo);
+            if (redo) {
+                br.rd = s_rd; br.bit = s_bit; br.hi = s_hi; br.lo = s_lo; br.pf = s_pf; ovf = s_ovf;
+                // the refill round inside the group acted on the speculative read position: forget the
+                // ring (words come from global memory until the next rounds have refilled it)
+                br.fill = s_rd & ~(kUnitWords - 1);
+                br.issued = kNoFill;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ring[U - 1 - j] = s_hist[j];
+            }
+        }
+        if (run_generic) {
             // ---- generic group: one sample at a time, shift-register history ----------------
             int32_t hist[NT];   // hist[j] = sample n-1-j
 #pragma unroll
@@ -699,7 +742,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             for (uint32_t n = n0; n < n0 + U; ++n) {
                 if (n != n0 && ((n - n0) % kRoundSteps) == 0)
                     ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
-                const bool ok = active && status == kFrameOK;
+                const bool ok = active && status == kFrameOK && redo;
                 const bool live = ok && n < bs;
                 if (ok && kind == 2 && !started && n >= order) {
                     start_residual();
@@ -725,10 +768,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 }
                 const int32_t pred = predict([&](int j) { return hist[j]; });
                 if (predicted) v = (int32_t)((uint32_t)v + (uint32_t)pred);
+                if (redo) {   // lanes that kept their fast-group result keep their history
 #pragma unroll
-                for (int j = NT - 1; j > 0; --j) hist[j] = hist[j - 1];
-                hist[0] = v;
-                emit(v, live && status == kFrameOK, n - tile_n0);
+                    for (int j = NT - 1; j > 0; --j) hist[j] = hist[j - 1];
+                    hist[0] = v;
+                }
+                emit(v, live && status == kFrameOK, n - tile_n0, std::false_type{});
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) ring[U - 1 - j] = hist[j];

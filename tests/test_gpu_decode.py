@@ -80,3 +80,24 @@ def test_host_buffer_entry_point(decoder, testdata):
     pcm, si, res = flac_amd.decode_file(os.path.join(testdata, STEREO), decoder)
     assert md5hex(pcm) == si.md5_signature
     assert res.frames_ok == 36
+
+
+def test_long_rice_codes(decoder):
+    """Rare full-scale spikes in quiet audio with one Rice partition per block give codes far longer than
+    the 32-bit window of the unrolled decode loop: the lanes that meet one are rolled back and redone by the
+    generic loop, their neighbours keep their results."""
+    rng = np.random.default_rng(5)
+    files, srcs = [], []
+    for ch, bps in ((2, 16), (1, 16), (2, 24)):
+        x = rng.integers(-40, 40, size=(4096 * 3 + 77, ch)).astype(np.int32)
+        spikes = rng.integers(0, x.shape[0], size=60)
+        x[spikes, rng.integers(0, ch, size=60)] = rng.choice([-(1 << (bps - 1)), (1 << (bps - 1)) - 1], size=60)
+        f, _ = synth.encode(x, bps, 44100, synth.options(4096, 8, force_partition_order=0, stereo_mode=0))
+        files.append(bytes(f))
+        srcs.append(synth.pack_pcm(x, bps))
+    pcms, res, infos = gpu_batch(decoder, files)
+    for f, p, src, si, r in zip(files, pcms, srcs, infos, res):
+        want, ost = oracle_decode(si, split_file(f)[1])
+        assert bytes(want) == src
+        assert np.array_equal(p, want)
+        assert r.frames_ok == ost.frames_ok == 4
