@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
-"""bench.py — decode throughput of libflacgpu on the BASELINE workload.
+"""bench.py — decode throughput of libflacgpu on the headline workload.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on;
-configs[1] is the two tiny reference fixtures and is a parity test, not a bench
-line): FILES (default 10 000) FLAC files of 60 s, 44.1 kHz, 16-bit stereo,
+Workload (the synthetic batch the metric is quoted on; the two tiny reference
+fixtures are a parity test, not a bench line): FILES (default 10 000) FLAC files of 60 s, 44.1 kHz, 16-bit stereo,
 block size 4096, fixed + LPC (order <= 12) subframes, Rice partition order <= 6.
 UNIQUE (default 256) distinct files are synthesised and encoded on the host by
 synth/ (seeded PRNG; no dataset exists offline) and replicated on the device to
@@ -43,7 +42,8 @@ def main():
     ap.add_argument("--files", type=int, default=10000)
     ap.add_argument("--unique", type=int, default=256)
     ap.add_argument("--seconds", type=float, default=60.0)
-    ap.add_argument("--cpu-files", type=int, default=64, help="files of the workload timed on the host CPU (0 = skip)")
+    ap.add_argument("--cpu-files", type=int, default=256, help="files of the workload timed on the host CPU (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU sample is decoded repeatedly for about this long")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
     args = ap.parse_args()
 
@@ -186,15 +186,18 @@ def main():
             o = oracle.StreamInfo()
             ctypes.memmove(ctypes.byref(o), ctypes.byref(infos[i]), ctypes.sizeof(o))
             oinfos.append(o)
-        t0 = time.perf_counter()
-        _, st = oracle.decode_batch(blob, offs, lens, oinfos, pcm, [i * pcm_bytes_per_file for i in range(ncpu)],
-                                    [pcm_bytes_per_file] * ncpu, nthreads=threads)
-        cpu_s = time.perf_counter() - t0
-        assert all(s.frames_ok == exp_frames for s in st)
+        outs = [i * pcm_bytes_per_file for i in range(ncpu)]
+        cpu_s, passes = 0.0, 0
+        while cpu_s < args.cpu_seconds and passes < 64:
+            t0 = time.perf_counter()
+            _, st = oracle.decode_batch(blob, offs, lens, oinfos, pcm, outs, [pcm_bytes_per_file] * ncpu, nthreads=threads)
+            cpu_s += time.perf_counter() - t0
+            passes += 1
+            assert all(s.frames_ok == exp_frames for s in st)
         got = d_out[:pcm_bytes_per_file].cpu().numpy()
         assert np.array_equal(got, pcm[:pcm_bytes_per_file]), "GPU PCM differs from the CPU oracle"
-        cpu = {"value": ncpu * nsamples * channels / cpu_s, "unit": "samples/s", "cores": threads, "kind": "port",
-               "sample": f"{ncpu} of the {unique} unique files ({ncpu * pcm_bytes_per_file / 1e6:.0f} MB PCM), "
+        cpu = {"value": passes * ncpu * nsamples * channels / cpu_s, "unit": "samples/s", "cores": threads, "kind": "port",
+               "sample": f"{ncpu} of the {unique} unique files ({ncpu * pcm_bytes_per_file / 1e6:.0f} MB PCM) decoded {passes} times, "
                          f"oracle/flac_oracle.c, {threads} threads, {cpu_s:.2f} s"}
 
     if rank == 0:
@@ -217,7 +220,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{nfiles} x {args.seconds:g} s 44.1 kHz 16-bit stereo FLAC, blocksize 4096, fixed+LPC(<=12), "
-                            f"{unique} unique files replicated in HBM (BASELINE configs[2])",
+                            f"{unique} unique files replicated in HBM",
                 "files_per_gpu": nfiles, "unique_files": unique,
                 "compressed_GB_per_gpu": comp_total / 1e9, "pcm_GB_per_gpu": pcm_total / 1e9,
             },

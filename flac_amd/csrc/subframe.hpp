@@ -721,7 +721,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             redo = rice_on && (starved || longest > 32);
 #endif
             // the two lanes of a stereo pair exchange samples: they are redone together
-            if (C == 2) redo = redo || __builtin_amdgcn_mov_dpp((int)redo, 0xB1, 0xF, 0xF, true) != 0;
+            // (the exchange must run in every lane, so it is not the right-hand side of a short-circuit ||)
+            if (C == 2) {
+                const int partner = __builtin_amdgcn_mov_dpp((int)redo, 0xB1, 0xF, 0xF, true);
+                redo = redo | (partner != 0);
+            }
             if (rice_on && !redo) part_rem -= U;
             run_generic = __any(redo);
             if (redo) {

@@ -9,7 +9,7 @@
  * optionally, the SeekpointBlocks (flacmeta.go:256-260).
  *
  * The reference has no FFI of its own; these are the entry points a cgo
- * binding of `package flac` would declare (INTEGRATION.md shows the binding).
+ * binding of `package flac` would declare.
  * Plain pointers and sizes only; every function returns an int status
  * (0 = FLACGPU_OK) and never aborts or throws across the boundary — malformed
  * input, which makes the reference panic (it indexes short slices without a

@@ -19,7 +19,7 @@ def _read(testdata, name):
 
 
 def test_fixtures_md5(decoder, testdata):
-    """BASELINE config 2: both reference fixtures, bit-exact against the MD5 the
+    """Both reference fixtures, bit-exact against the MD5 the
     reference's tests assert (flacmeta_test.go:37, :121)."""
     files = [_read(testdata, MONO), _read(testdata, STEREO)]
     pcms, res, infos = gpu_batch(decoder, files)

@@ -1,0 +1,41 @@
+"""The multi-GPU path is file sharding with a gather of small result rows.  Here it runs at world size 2
+over gloo on CPU (torch.distributed.run, one process per rank, as bench.py is launched on a GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from flac_amd import sharding
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_indices_partition():
+    for n in (0, 1, 7, 8, 10000):
+        for world in (1, 2, 3, 8):
+            seen = sorted(i for r in range(world) for i in sharding.shard_indices(n, r, world))
+            assert seen == list(range(n))
+            sizes = [len(sharding.shard_indices(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_indices(4, 2, 2)
+
+
+def _run(world, out, port):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "_shard_worker.py"), out]
+    subprocess.run(cmd, check=True, env=env, timeout=240, cwd=os.path.dirname(HERE))
+    return json.load(open(out))
+
+
+def test_two_ranks_equal_one(tmp_path):
+    one = _run(1, str(tmp_path / "w1.json"), 29611)
+    two = _run(2, str(tmp_path / "w2.json"), 29612)
+    assert two["world"] == 2 and two["mine"] == list(range(0, len(one["table"]), 2))
+    t1, t2 = np.array(one["table"]), np.array(two["table"])
+    assert np.array_equal(t1, t2)
+    assert (t1[:, 2] == t1[:, 1]).all() and (t1[:, 1] > 0).all()   # every frame of every stream decoded
