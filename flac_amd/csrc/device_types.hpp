@@ -16,7 +16,7 @@ struct StreamDev {
     uint32_t max_bs;         // STREAMINFO MaxBlockSize
     uint32_t cand_begin;     // [cand_begin, cand_end) in the candidate arrays
     uint32_t cand_end;
-    uint32_t pending;        // some span of this stream failed its CRC-16
+    uint32_t pending;        // some frame of this stream spans more than one candidate
     uint8_t  channels;
     uint8_t  bps;
     uint8_t  bytes_ps;       // ceil(bps / 8)
@@ -55,6 +55,7 @@ struct CandArrays {
     uint16_t *segcrc;   // CRC-16 of [goff[r], goff[r+1]) (or to the end of the stream)
     uint32_t *seglen;   // its length
     uint32_t *subpos;   // [r * 8 + c]: bit offset of subframe c from the frame's aligned word base
+    uint32_t *next;     // candidate that follows the frame starting here
 };
 
 constexpr int kFrameOK = 0, kFrameBadCrc16 = 1, kFrameBadSubframe = 2, kFrameTruncated = 3,

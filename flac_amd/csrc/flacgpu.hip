@@ -40,8 +40,8 @@ struct flacgpu_handle {
     uint32_t flags = 0;
     hipStream_t own_stream = nullptr;
     std::string err;
-    DevBuf streams, results, mask, tile_count, tile_base, counter, crc_tables;
-    DevBuf goff, num, info, stream, len, status, segcrc, seglen, subpos;
+    DevBuf streams, results, mask, bitmap, tile_count, tile_base, group_sum, group_base, counter, crc_tables;
+    DevBuf goff, num, info, stream, len, status, segcrc, seglen, subpos, next;
     uint32_t cand_cap = 0;
     hipEvent_t ev[EV_COUNT] = {};
     flacgpu_timing timing = {};
@@ -88,6 +88,7 @@ CandArrays cand_arrays(flacgpu_handle *h)
     c.goff = (uint64_t *)h->goff.p; c.num = (uint64_t *)h->num.p; c.info = (uint32_t *)h->info.p;
     c.stream = (uint32_t *)h->stream.p; c.len = (uint32_t *)h->len.p; c.status = (int32_t *)h->status.p;
     c.segcrc = (uint16_t *)h->segcrc.p; c.seglen = (uint32_t *)h->seglen.p; c.subpos = (uint32_t *)h->subpos.p;
+    c.next = (uint32_t *)h->next.p;
     return c;
 }
 
@@ -105,6 +106,7 @@ int reserve_candidates(flacgpu_handle *h, uint32_t n)
     if ((rc = reserve(h, h->segcrc, cap * 2))) return rc;
     if ((rc = reserve(h, h->seglen, cap * 4))) return rc;
     if ((rc = reserve(h, h->subpos, cap * 8 * 4))) return rc;
+    if ((rc = reserve(h, h->next, cap * 4))) return rc;
     h->cand_cap = (uint32_t)cap;
     return FLACGPU_OK;
 }
@@ -150,23 +152,26 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     const uint64_t n_tiles64 = (in_bytes + kScanTileBytes - 1) / kScanTileBytes;
     if (n_tiles64 == 0 || n_tiles64 > 0x7FFFFFFFull) return fail(h, FLACGPU_ERR_ARG, "input size out of range");
     const uint32_t n_tiles = (uint32_t)n_tiles64;
-    const uint64_t n_mask64 = (in_bytes + 63) / 64;
+    const uint32_t n_groups = (n_tiles + kPrefixGroup - 1) / kPrefixGroup;
     if ((rc = reserve(h, h->streams, (size_t)n * sizeof(StreamDev)))) return rc;
     if ((rc = reserve(h, h->results, (size_t)n * sizeof(ResultDev)))) return rc;
-    if ((rc = reserve(h, h->mask, n_mask64 * 8))) return rc;
+    if ((rc = reserve(h, h->mask, (size_t)n_tiles * kTileGranules * 2))) return rc;
+    if ((rc = reserve(h, h->bitmap, (size_t)n_tiles * kTileChunks * 8))) return rc;
     if ((rc = reserve(h, h->tile_count, (size_t)n_tiles * 4))) return rc;
     if ((rc = reserve(h, h->tile_base, (size_t)n_tiles * 4))) return rc;
+    if ((rc = reserve(h, h->group_sum, (size_t)n_groups * 4))) return rc;
+    if ((rc = reserve(h, h->group_base, (size_t)n_groups * 4))) return rc;
     if ((rc = reserve(h, h->counter, 64))) return rc;
 
     HIP_TRY(hipMemcpyAsync(h->streams.p, h->h_streams.data(), (size_t)n * sizeof(StreamDev), hipMemcpyHostToDevice, st));
-    // granules past the end of the input are never written by the scan: clear the last mask word
-    HIP_TRY(hipMemsetAsync((uint8_t *)h->mask.p + (n_mask64 - 1) * 8, 0, 8, st));
     mark(h, EV_START, st);
-    k_scan_mask<<<n_tiles, 256, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (uint16_t *)h->mask.p,
-                                         (uint32_t *)h->tile_count.p);
+    k_scan_tiles<<<n_tiles, 256, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (uint16_t *)h->mask.p,
+                                          (uint64_t *)h->bitmap.p, (uint32_t *)h->tile_count.p);
     mark(h, EV_SCAN, st);
-    k_tile_prefix<<<1, 1024, 0, st>>>((const uint32_t *)h->tile_count.p, (uint32_t *)h->tile_base.p, n_tiles,
-                                      (uint32_t *)h->counter.p);
+    k_tile_prefix_local<<<n_groups, 1024, 0, st>>>((const uint32_t *)h->tile_count.p, (uint32_t *)h->tile_base.p, n_tiles,
+                                                   (uint32_t *)h->group_sum.p);
+    k_tile_prefix_groups<<<1, 1024, 0, st>>>((const uint32_t *)h->group_sum.p, (uint32_t *)h->group_base.p, n_groups,
+                                             (uint32_t *)h->counter.p);
     uint32_t n_cand = 0;
     HIP_TRY(hipMemcpyAsync(&n_cand, h->counter.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -174,9 +179,10 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     if ((rc = reserve_candidates(h, n_cand ? n_cand : 1))) return rc;
     CandArrays c = cand_arrays(h);
     if (n_cand) {
-        k_compact<<<n_tiles, 256, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (const uint64_t *)h->mask.p,
-                                           n_mask64, (const uint32_t *)h->tile_count.p, (const uint32_t *)h->tile_base.p,
-                                           h->cand_cap, c);
+        k_compact<<<(n_tiles + 3) / 4, 256, 0, st>>>((const uint16_t *)h->mask.p, (const uint64_t *)h->bitmap.p,
+                                                     (const uint32_t *)h->tile_count.p, (const uint32_t *)h->tile_base.p,
+                                                     (const uint32_t *)h->group_base.p, n_tiles, h->cand_cap, c.goff);
+        k_cand_fill<<<(n_cand + 255) / 256, 256, 0, st>>>(d_in, (const StreamDev *)h->streams.p, n, c, n_cand);
     }
     k_stream_ranges<<<(n + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, n, c.goff, n_cand);
     mark(h, EV_COMPACT, st);
@@ -187,8 +193,9 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     }
     mark(h, EV_CRC, st);
     if (n_cand) {
-        k_resolve_fast<<<(n_cand + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, c, n_cand);
-        k_resolve_slow<<<(n + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, n, c);
+        k_resolve_chain<<<(n_cand + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, c, n_cand,
+                                                              (const uint16_t *)h->crc_tables.p + kCrcPow2);
+        k_resolve_walk<<<(n + 3) / 4, 256, 0, st>>>((const StreamDev *)h->streams.p, n, c);
     }
     mark(h, EV_RESOLVE, st);
     HIP_TRY(hipMemcpyAsync(h->h_streams.data(), h->streams.p, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost, st));
@@ -265,8 +272,9 @@ void flacgpu_destroy(flacgpu_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    DevBuf *all[] = {&h->streams, &h->results, &h->mask, &h->tile_count, &h->tile_base, &h->counter, &h->crc_tables, &h->goff, &h->num,
-                     &h->info, &h->stream, &h->len, &h->status, &h->segcrc, &h->seglen, &h->subpos};
+    DevBuf *all[] = {&h->streams, &h->results, &h->mask, &h->bitmap, &h->tile_count, &h->tile_base, &h->group_sum, &h->group_base,
+                     &h->counter, &h->crc_tables, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
+                     &h->seglen, &h->subpos, &h->next};
     for (DevBuf *b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -381,9 +389,12 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
         p.in = (const uint8_t *)d_in; p.in_vecs = in_vecs; p.out = (uint8_t *)d_out;
         p.streams = (const StreamDev *)h->streams.p; p.c = c;
         p.r_begin = r.r_begin; p.r_end = r.r_end; p.C = r.C; p.B = r.B;
+        p.class_flags = (uint32_t *)h->counter.p + 4;
+        p.check_flag = 0;
+        HIP_TRY(hipMemsetAsync(p.class_flags, 0, 6 * sizeof(uint32_t), st));
         // every predictor-length class is launched over the same grid; a wave runs in exactly one
 #define FLACGPU_LAUNCH(MO, W, S) \
-        k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C, r.B), st>>>(p)
+        k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C, r.B), st>>>(p); p.check_flag = 1
         if (r.C == 2 && r.B == 2) {
             FLACGPU_LAUNCH(12, 0, true); FLACGPU_LAUNCH(32, 0, true); FLACGPU_LAUNCH(12, 1, true);
             FLACGPU_LAUNCH(32, 1, true); FLACGPU_LAUNCH(12, 2, true); FLACGPU_LAUNCH(32, 2, true);

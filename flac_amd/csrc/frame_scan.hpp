@@ -1,14 +1,16 @@
 // frame_scan.hpp — frame discovery kernels (gfx950).
 //
-//   k_scan_mask     every byte of the batch is tested for the sync pair
+//   k_scan_tiles    every byte of the batch is tested for the sync pair
 //                   0xFF 0xF8|0xF9; a hit is kept when the header that starts
 //                   there is valid for its stream (no reserved code, coded
 //                   number well-formed, CRC-8 matches, channel count / sample
-//                   size / block size agree with STREAMINFO).  Output: one mask
-//                   bit per input byte (uint16 per 16-byte granule) and a
-//                   candidate count per 64 KiB tile.
-//   k_tile_prefix   exclusive prefix sum of the tile counts.
-//   k_compact       ordered candidate list (offset, header fields) from the mask.
+//                   size / block size agree with STREAMINFO).  Output: a sparse
+//                   mask with one bit per input byte (uint16 per 16-byte granule,
+//                   written only where not zero), a bitmap of the granules whose
+//                   mask entry is set, and a candidate count per 64 KiB tile.
+//   k_tile_prefix_* exclusive prefix sum of the tile counts (two levels).
+//   k_compact       ordered candidate offsets from the bitmap and the mask.
+//   k_cand_fill     header fields of every candidate.
 //   k_stream_ranges candidate range of every stream.
 //   k_crc16_spans   CRC-16 of the bytes between consecutive candidates; one
 //                   wave per span, lanes load consecutive 16-byte vectors and
@@ -16,7 +18,8 @@
 //                   in GF(2)[x] / 0x18005.
 //   k_resolve_*     candidate i is a frame when the CRC-16 of a span that starts
 //                   at i and ends at one of the next kLookahead candidates (or the
-//                   end of the stream) is zero; output range checks.
+//                   end of the stream) is zero; candidates inside an accepted frame
+//                   are struck out; output range checks.
 //
 // All of it is HBM-bound byte/integer work: loads are 16 bytes per lane,
 // coalesced; per-candidate work (header parse, CRC-8) is rare and goes straight
@@ -125,135 +128,264 @@ __device__ inline uint32_t movemask4(uint32_t m) { return (((m >> 7) * 0x0020408
 
 // ------------------------------------------------------------------ scan ---
 
-__global__ __launch_bounds__(256) void k_scan_mask(const uint8_t *__restrict__ in, uint64_t in_bytes,
-                                                   const StreamDev *__restrict__ streams, uint32_t n_streams,
-                                                   uint16_t *__restrict__ mask, uint32_t *__restrict__ tile_count)
+constexpr uint32_t kChunkBytes = 1024;                            // one wave step: 64 lanes x 16 bytes
+constexpr uint32_t kTileChunks = kScanTileBytes / kChunkBytes;    // 64
+constexpr uint32_t kTileGranules = kScanTileBytes / kGranule;     // 4096
+constexpr uint32_t kHitCap = 2048;                                // sync hits a workgroup queues for validation
+constexpr uint32_t kPrefixGroup = 1024;                           // tiles per first-level prefix group
+
+// Lane mask of the lanes whose low / high 16 bits of x equal c.  The sub-dword operand select does the
+// field extraction inside the compare, and the result lands in a scalar register pair.
+__device__ inline uint64_t eq_lo16(uint32_t x, uint32_t c)
 {
-    __shared__ uint32_t s_count;
-    if (threadIdx.x == 0) s_count = 0;
+    uint64_t m;
+    asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:DWORD" : "=s"(m) : "v"(x), "v"(c));
+    return m;
+}
+__device__ inline uint64_t eq_hi16(uint32_t x, uint32_t c)
+{
+    uint64_t m;
+    asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:DWORD" : "=s"(m) : "v"(x), "v"(c));
+    return m;
+}
+
+// Stream that contains global byte offset g among streams [lo, hi), or -1.
+__device__ inline int find_stream_in(const StreamDev *streams, uint32_t lo, uint32_t hi, uint64_t g)
+{
+    const uint32_t first = lo;
+    while (lo < hi) {   // first stream with in_off > g
+        const uint32_t mid = (lo + hi) >> 1;
+        if (streams[mid].in_off <= g) lo = mid + 1; else hi = mid;
+    }
+    if (lo == first) return -1;
+    const StreamDev &s = streams[lo - 1];
+    return (g - s.in_off < s.in_len) ? (int)(lo - 1) : -1;
+}
+
+// One workgroup per 64 KiB tile.
+//   1. detect: each wave steps over its 16 KiB in 1 KiB chunks, four chunks loaded ahead.  A sync code
+//      at byte j is the 16-bit field (byte j, byte j+1) with (field & 0xFEFF) == 0xF8FF; sixteen
+//      sub-dword compares per chunk give the hit lanes of every byte position as scalar masks, so the
+//      common chunk without any sync code costs no per-lane work beyond the compares.
+//   2. queue: hit positions go to a list in LDS (a tile with more hits than the list holds is redone
+//      byte by byte; that does not happen with audio).
+//   3. validate: the queued positions are checked densely, one per thread (header fields, coded number,
+//      CRC-8, agreement with STREAMINFO); survivors set their bit in the tile's byte mask in LDS.
+//   4. write-out: mask words that are not zero go to `mask16` (sparse: the rest of the array is not
+//      written and never read), `bitmap64` gets one bit per 16-byte granule ("mask16 entry is valid and
+//      not zero"), `tile_count` the number of candidates.
+__global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                    const StreamDev *__restrict__ streams, uint32_t n_streams,
+                                                    uint16_t *__restrict__ mask16, uint64_t *__restrict__ bitmap64,
+                                                    uint32_t *__restrict__ tile_count)
+{
+    __shared__ uint32_t s_mask[kScanTileBytes / 32];
+    __shared__ uint16_t s_hits[kHitCap];
+    __shared__ uint32_t s_nhits, s_count;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_mask[tid * 8 + k] = 0;
+    if (tid == 0) { s_nhits = 0; s_count = 0; }
     __syncthreads();
     const uint64_t tile_base = (uint64_t)blockIdx.x * kScanTileBytes;
-    uint32_t mine = 0;
-    constexpr int iters = kScanTileBytes / kGranule / 256;
-#pragma unroll 2
-    for (int it = 0; it < iters; ++it) {
-        const uint64_t g0 = tile_base + ((uint64_t)it * 256 + threadIdx.x) * kGranule;
-        if (g0 >= in_bytes) break;
-        uint32_t w[5];
-        if (g0 + kGranule + 1 <= in_bytes) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(in + g0);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            w[4] = in[g0 + kGranule];
-        } else {
-            // last granule of the batch: byte loads, zero padded
-            for (int k = 0; k < 5; ++k) {
-                uint32_t x = 0;
-                for (int j = 0; j < 4; ++j) {
-                    const uint64_t a = g0 + (uint64_t)(4 * k + j);
-                    if (a < in_bytes) x |= (uint32_t)in[a] << (8 * j);
-                }
-                w[k] = x;
-            }
-        }
-        // FF[i]: byte i == 0xFF.  F8[i]: (byte i & 0xFE) == 0xF8.  A candidate starts at i when FF[i] & F8[i+1].
-        uint32_t hits = 0;
+    // streams that can own a byte of this tile: [s_lo, s_hi)
+    uint32_t s_lo, s_hi;
+    {
+        uint32_t lo = 0, hi = n_streams;   // first stream with in_off > tile_base
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (streams[mid].in_off <= tile_base) lo = mid + 1; else hi = mid; }
+        s_lo = lo ? lo - 1 : 0;
+        hi = n_streams;                    // first stream with in_off >= end of tile
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (streams[mid].in_off < tile_base + kScanTileBytes) lo = mid + 1; else hi = mid; }
+        s_hi = lo;
+    }
+    auto validate = [&](uint32_t off) {
+        const uint64_t g = tile_base + off;
+        const int si = find_stream_in(streams, s_lo, s_hi, g);
+        if (si < 0) return;
+        const StreamDev s = streams[si];
+        FrameHdr h;
+        if (parse_frame_header(in + g, s.in_off + s.in_len - g, s, h)) atomicOr(&s_mask[off >> 5], 1u << (off & 31));
+    };
+
+    const uint32_t field = 0xF8FFu;
+    for (uint32_t round = 0; round < 4; ++round) {
+        const uint32_t chunk0 = wave * 16 + round * 4;
+        uint4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t ff = zero_bytes(~w[k]);
-            const uint32_t f8a = zero_bytes((w[k] & 0xFEFEFEFEu) ^ 0xF8F8F8F8u);
-            const uint32_t f8b = zero_bytes((w[k + 1] & 0xFEFEFEFEu) ^ 0xF8F8F8F8u);
-            const uint32_t next = (f8a >> 8) | (f8b << 24);
-            hits |= movemask4(ff & next) << (4 * k);
+            const uint64_t g = tile_base + (uint64_t)(chunk0 + k) * kChunkBytes + lane * kGranule;
+            v[k] = g < in_bytes ? *reinterpret_cast<const uint4 *>(in + g) : uint4{0u, 0u, 0u, 0u};
         }
-        uint32_t keep = 0;
-        while (hits) {
-            const uint32_t i = __builtin_ctz(hits);
-            hits &= hits - 1;
-            const uint64_t g = g0 + i;
-            const int si = find_stream(streams, n_streams, g);
-            if (si >= 0) {
-                const StreamDev s = streams[si];
-                FrameHdr h;
-                if (parse_frame_header(in + g, s.in_off + s.in_len - g, s, h)) keep |= 1u << i;
+        const uint64_t g_after = tile_base + (uint64_t)(chunk0 + 4) * kChunkBytes;
+        const uint32_t byte_after = g_after < in_bytes ? in[g_after] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // first byte of the granule that follows this lane's
+            uint32_t nb = (uint32_t)__shfl_down((int)v[k].x, 1);
+            const uint32_t wrap = k < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k < 3 ? k + 1 : 3].x) : byte_after;
+            if (lane == 63) nb = wrap;
+            const uint32_t w[5] = {v[k].x, v[k].y, v[k].z, v[k].w, nb};
+            uint64_t m[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t a = w[q] & 0xFEFFFEFFu;                                            // bytes 4q .. 4q+3
+                const uint32_t u = __builtin_amdgcn_alignbit(w[q + 1], w[q], 8) & 0xFEFFFEFFu;    // bytes 4q+1 .. 4q+4
+                m[4 * q + 0] = eq_lo16(a, field);
+                m[4 * q + 1] = eq_lo16(u, field);
+                m[4 * q + 2] = eq_hi16(a, field);
+                m[4 * q + 3] = eq_hi16(u, field);
+            }
+            uint64_t any = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) any |= m[j];
+            if (any) {
+                uint32_t hits = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) hits |= (uint32_t)((m[j] >> lane) & 1) << j;
+                if (hits) {
+                    uint32_t slot = atomicAdd(&s_nhits, (uint32_t)__builtin_popcount(hits));
+                    const uint32_t off0 = (chunk0 + k) * kChunkBytes + lane * kGranule;
+                    while (hits) {
+                        const uint32_t off = off0 + __builtin_ctz(hits);
+                        hits &= hits - 1;
+                        if (slot < kHitCap) s_hits[slot] = (uint16_t)off;   // else: the whole tile is redone below
+                        ++slot;
+                    }
+                }
             }
         }
-        mask[g0 / kGranule] = (uint16_t)keep;
-        mine += __builtin_popcount(keep);
     }
-    if (mine) atomicAdd(&s_count, mine);
     __syncthreads();
-    if (threadIdx.x == 0) tile_count[blockIdx.x] = s_count;
+    const uint32_t nh = s_nhits;
+    if (nh <= kHitCap) {
+        for (uint32_t i = tid; i < nh; i += 256) validate(s_hits[i]);
+    } else {
+        // more sync codes than the list holds (not audio: a crafted or degenerate input): every thread
+        // tests the 256 byte positions it owns one by one
+        for (uint32_t i = 0; i < 256; ++i) {
+            const uint32_t off = tid * 256 + i;
+            const uint64_t g = tile_base + off;
+            if (g + 1 < in_bytes && in[g] == 0xFF && (in[g + 1] & 0xFE) == 0xF8) validate(off);
+        }
+    }
+    __syncthreads();
+
+    // thread t owns granules 16t .. 16t+15 = mask words 8t .. 8t+7
+    uint32_t nz = 0, cnt = 0;
+    const uint64_t granule0 = (uint64_t)blockIdx.x * kTileGranules + tid * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t x = s_mask[tid * 8 + k];
+        if (x) {
+            cnt += __builtin_popcount(x);
+            if (x & 0xFFFFu) { mask16[granule0 + 2 * k] = (uint16_t)x; nz |= 1u << (2 * k); }
+            if (x >> 16) { mask16[granule0 + 2 * k + 1] = (uint16_t)(x >> 16); nz |= 2u << (2 * k); }
+        }
+    }
+    // four threads' 16 flags make one 64-bit bitmap word (1 KiB of input)
+    const uint32_t base = lane & ~3u;
+    const uint32_t n0 = (uint32_t)__shfl((int)nz, (int)base), n1 = (uint32_t)__shfl((int)nz, (int)base + 1),
+                   n2 = (uint32_t)__shfl((int)nz, (int)base + 2), n3 = (uint32_t)__shfl((int)nz, (int)base + 3);
+    if ((lane & 3) == 0)
+        bitmap64[(uint64_t)blockIdx.x * kTileChunks + (tid >> 2)] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32);
+    if (cnt) atomicAdd(&s_count, cnt);
+    __syncthreads();
+    if (tid == 0) tile_count[blockIdx.x] = s_count;
 }
 
-// Exclusive prefix sum of n counts by one workgroup of 1024 threads; total -> *total.
-__global__ __launch_bounds__(1024) void k_tile_prefix(const uint32_t *__restrict__ count, uint32_t *__restrict__ base,
-                                                      uint32_t n, uint32_t *__restrict__ total)
+// Exclusive prefix sum of the tile counts in two levels: within groups of kPrefixGroup tiles (one
+// workgroup each), then over the group totals (one workgroup).  base of tile t = tile_base[t] + group_base[t / kPrefixGroup].
+__device__ inline uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total)
 {
-    __shared__ uint32_t s_part[1024];
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t a = threadIdx.x * per, b = min(a + per, n);
-    uint32_t sum = 0;
-    for (uint32_t i = a; i < b; ++i) sum += count[i];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
+        if (lane >= (uint32_t)d) inc += o;
     }
-    uint32_t run = s_part[threadIdx.x] - sum;
-    for (uint32_t i = a; i < b; ++i) { base[i] = run; run += count[i]; }
-    if (threadIdx.x == 1023) *total = s_part[1023];
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < 16; ++w) { const uint32_t x = s_wave[w]; if (w < wave) before += x; all += x; }
+    __syncthreads();
+    total = all;
+    return before + inc - v;
 }
 
-// One workgroup per tile: 4096 mask words (uint16) = 1024 uint64; thread t owns words 4t..4t+3.
-__global__ __launch_bounds__(256) void k_compact(const uint8_t *__restrict__ in, uint64_t in_bytes,
-                                                 const StreamDev *__restrict__ streams, uint32_t n_streams,
-                                                 const uint64_t *__restrict__ mask64, uint64_t n_mask64,
-                                                 const uint32_t *__restrict__ tile_count,
-                                                 const uint32_t *__restrict__ tile_base, uint32_t cap, CandArrays c)
+__global__ __launch_bounds__(1024) void k_tile_prefix_local(const uint32_t *__restrict__ count, uint32_t *__restrict__ base,
+                                                            uint32_t n, uint32_t *__restrict__ group_sum)
 {
-    if (tile_count[blockIdx.x] == 0) return;
-    __shared__ uint32_t s_scan[256];
-    const uint64_t w0 = (uint64_t)blockIdx.x * (kScanTileBytes / 64) + (uint64_t)threadIdx.x * 4;
-    uint64_t m[4];
+    __shared__ uint32_t s_wave[16];
+    const uint32_t i = blockIdx.x * kPrefixGroup + threadIdx.x;
+    const uint32_t v = i < n ? count[i] : 0;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
+    if (i < n) base[i] = ex;
+    if (threadIdx.x == 0) group_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_prefix_groups(const uint32_t *__restrict__ group_sum, uint32_t *__restrict__ group_base,
+                                                             uint32_t n_groups, uint32_t *__restrict__ total_out)
+{
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += 1024) {
+        const uint32_t i = g0 + threadIdx.x;
+        const uint32_t v = i < n_groups ? group_sum[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
+        if (i < n_groups) group_base[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+// Ordered candidate offsets from the bitmap and the sparse mask: one wave per tile, lane l owns
+// bitmap word l (1 KiB of input).
+__global__ __launch_bounds__(256) void k_compact(const uint16_t *__restrict__ mask16, const uint64_t *__restrict__ bitmap64,
+                                                 const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ tile_base,
+                                                 const uint32_t *__restrict__ group_base, uint32_t n_tiles, uint32_t cap,
+                                                 uint64_t *__restrict__ goff)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles || tile_count[tile] == 0) return;
+    const uint64_t word = (uint64_t)tile * kTileChunks + lane;
+    const uint64_t bits = bitmap64[word];
     uint32_t cnt = 0;
+    for (uint64_t b = bits; b; b &= b - 1) cnt += __builtin_popcount(mask16[word * 64 + __builtin_ctzll(b)]);
+    uint32_t inc = cnt;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        m[k] = (w0 + k < n_mask64) ? mask64[w0 + k] : 0;
-        cnt += __builtin_popcountll(m[k]);
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
+        if (lane >= (uint32_t)d) inc += o;
     }
-    s_scan[threadIdx.x] = cnt;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-        uint32_t v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
-        __syncthreads();
-        s_scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t r = tile_base[blockIdx.x] + s_scan[threadIdx.x] - cnt;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        uint64_t bits = m[k];
-        while (bits) {
-            const uint32_t i = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            const uint64_t g = (w0 + k) * 64 + i;
-            if (r < cap) {
-                const int si = find_stream(streams, n_streams, g);
-                const StreamDev s = streams[si];
-                FrameHdr h;
-                parse_frame_header(in + g, s.in_off + s.in_len - g, s, h);
-                c.goff[r] = g;
-                c.num[r] = h.num;
-                c.info[r] = pack_info(h.bs, h.hdrlen, h.ch_assign, h.bps, h.variable);
-                c.stream[r] = (uint32_t)si;
-            }
+    uint32_t r = tile_base[tile] + group_base[tile / kPrefixGroup] + inc - cnt;
+    for (uint64_t b = bits; b; b &= b - 1) {
+        const uint64_t granule = word * 64 + __builtin_ctzll(b);
+        for (uint32_t m = mask16[granule]; m; m &= m - 1) {
+            if (r < cap) goff[r] = granule * kGranule + __builtin_ctz(m);
             ++r;
         }
     }
+}
+
+// Header fields of every candidate, one thread per candidate.
+__global__ __launch_bounds__(256) void k_cand_fill(const uint8_t *__restrict__ in, const StreamDev *__restrict__ streams,
+                                                   uint32_t n_streams, CandArrays c, uint32_t n_cand)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_cand) return;
+    const uint64_t g = c.goff[r];
+    const int si = find_stream(streams, n_streams, g);
+    const StreamDev s = streams[si < 0 ? 0 : si];
+    FrameHdr h;
+    h.bs = 0; h.hdrlen = 0; h.ch_assign = 0; h.bps = 1; h.variable = 0; h.num = 0;
+    if (si >= 0) parse_frame_header(in + g, s.in_off + s.in_len - g, s, h);
+    c.num[r] = h.num;
+    c.info[r] = pack_info(h.bs, h.hdrlen, h.ch_assign, h.bps, h.variable);
+    c.stream[r] = (uint32_t)(si < 0 ? 0 : si);
 }
 
 // cand_begin / cand_end of every stream by binary search over the candidate offsets.
@@ -316,8 +448,9 @@ __device__ inline void crc16_pow_table(uint16_t *pow2)
 //   skip[h][v]   (2 x 256)   multiplication of a 16-bit remainder by x^(8 * 1024), split by byte
 //   lanew[l]     (64)        x^(8 * 16 * (63 - l))
 //   remw[r]      (16)        x^(8 * r)
+//   pow2[k]      (32)        x^(8 * 2^k), for gf_xpow8
 constexpr int kCrcPiece = 0, kCrcSkip = 16 * 256, kCrcLane = kCrcSkip + 512, kCrcRem = kCrcLane + 64,
-              kCrcTableEntries = kCrcRem + 16;
+              kCrcPow2 = kCrcRem + 16, kCrcTableEntries = kCrcPow2 + 32;
 
 __global__ void k_crc16_build_tables(uint16_t *t)
 {
@@ -334,8 +467,10 @@ __global__ void k_crc16_build_tables(uint16_t *t)
             v = gf_mulmod(hsel ? byte << 8 : byte, gf_xpow8(1024, s_pow2));
         } else if (i < (uint32_t)kCrcRem) {
             v = gf_xpow8(16 * (63 - (i - kCrcLane)), s_pow2);
-        } else {
+        } else if (i < (uint32_t)kCrcPow2) {
             v = gf_xpow8(i - kCrcRem, s_pow2);
+        } else {
+            v = s_pow2[i - kCrcPow2];
         }
         t[i] = (uint16_t)v;
     }
@@ -429,50 +564,56 @@ __device__ inline int range_status(const StreamDev &s, uint32_t info, uint64_t n
     return kFrameOK;
 }
 
-// Fast path, one thread per candidate: a span with zero CRC-16 is a frame.
-__global__ void k_resolve_fast(StreamDev *streams, CandArrays c, uint32_t n_cand)
+// One thread per candidate: the frame that starts here, if any.  The CRC-16 of [r, j+1) follows from the
+// span remainders: crc([r, j+1)) = crc([r, j)) * x^(8 * seglen[j]) + segcrc[j].  next[r] = the candidate
+// after the frame (r + 1 when no end point closes the CRC).
+__global__ __launch_bounds__(256) void k_resolve_chain(StreamDev *streams, CandArrays c, uint32_t n_cand,
+                                                       const uint16_t *__restrict__ pow2)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_cand) return;
     const uint32_t si = c.stream[r];
-    c.len[r] = c.seglen[r];
-    if (c.segcrc[r] == 0) {
+    uint32_t crc = c.segcrc[r], total = c.seglen[r], found = crc == 0 ? r + 1 : 0;
+    if (!found) {
+        const uint32_t cand_end = streams[si].cand_end;
+        for (uint32_t j = r + 1; j < r + kLookahead && j < cand_end; ++j) {
+            const uint32_t sl = c.seglen[j];
+            crc = crc16_shift(crc, sl, pow2) ^ c.segcrc[j];
+            total += sl;
+            if (crc == 0) { found = j + 1; break; }
+        }
+    }
+    if (found) {
+        c.len[r] = total;
         c.status[r] = range_status(streams[si], c.info[r], c.num[r]);
+        c.next[r] = found;
+        if (found != r + 1) streams[si].pending = 1;   // candidates inside this frame have to be struck out
     } else {
+        c.len[r] = c.seglen[r];
         c.status[r] = kFrameBadCrc16;
-        streams[si].pending = 1;
+        c.next[r] = r + 1;
     }
 }
 
-// Slow path, one thread per stream that has a span with a non-zero CRC-16: walk
-// the candidates in order, trying up to kLookahead end points for each.
-__global__ void k_resolve_slow(StreamDev *streams, uint32_t n_streams, CandArrays c)
+// One wave per stream in which some frame spans several candidates: follow next[] from the stream's
+// first candidate; candidates the walk does not visit lie inside an accepted frame.
+__global__ __launch_bounds__(256) void k_resolve_walk(const StreamDev *__restrict__ streams, uint32_t n_streams, CandArrays c)
 {
-    __shared__ uint16_t s_pow2[32];
-    crc16_pow_table(s_pow2);
-    __syncthreads();
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= n_streams || !streams[s].pending) return;
-    const StreamDev st = streams[s];
-    uint32_t cur = st.cand_begin;
-    while (cur < st.cand_end) {
-        uint32_t crc = 0, total = 0, found = 0;
-        for (uint32_t j = cur; j < cur + kLookahead && j < st.cand_end; ++j) {
-            // crc([cur, j+1)) = crc([cur, j)) * x^(8 * seglen[j]) + segcrc[j]
-            crc = crc16_shift(crc, c.seglen[j], s_pow2) ^ c.segcrc[j];
-            total += c.seglen[j];
-            if (crc == 0) { found = j + 1; break; }
+    const uint32_t begin = streams[s].cand_begin, end = streams[s].cand_end;
+    uint32_t cur = begin;   // wave-uniform
+    for (uint32_t base = begin; base < end; base += 64) {
+        const uint32_t r = base + lane;
+        const uint32_t nx = r < end ? c.next[r] : 0xFFFFFFFFu;
+        uint64_t reach = 0;
+        while (cur < end && cur - base < 64) {
+            const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur - base));
+            reach |= 1ull << i;
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)i);
         }
-        if (found) {
-            c.len[cur] = total;
-            c.status[cur] = range_status(st, c.info[cur], c.num[cur]);
-            for (uint32_t j = cur + 1; j < found; ++j) { c.status[j] = kFrameSkipped; c.len[j] = 0; }
-            cur = found;
-        } else {
-            c.len[cur] = c.seglen[cur];
-            c.status[cur] = kFrameBadCrc16;
-            ++cur;
-        }
+        if (r < end && !((reach >> lane) & 1)) { c.status[r] = kFrameSkipped; c.len[r] = 0; }
     }
 }
 

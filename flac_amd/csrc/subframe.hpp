@@ -396,6 +396,8 @@ struct DecodeParams {
     uint32_t r_begin, r_end;
     uint32_t C;            // channels of every frame in [r_begin, r_end)
     uint32_t B;            // bytes per sample in the output
+    uint32_t *class_flags; // [6]: set when some wave of the run belongs to that (taps, arithmetic) class
+    uint32_t check_flag;   // leave at once when this instantiation's flag is not set
 };
 
 __device__ inline uint32_t wave_max_u32(uint32_t v)
@@ -436,6 +438,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int U = class_unroll(NT);
+    // The instantiation launched first runs every wave and flags the classes its waves turn out to belong
+    // to; the launches that follow are over in microseconds when no wave is theirs.
+    if (p.check_flag && p.class_flags[(NT == 12 ? 0 : 1) + 2 * ARITH] == 0) return;
     const uint32_t C = STEREO16 ? 2u : p.C, B = STEREO16 ? 2u : p.B;
     const uint32_t CB = C * B;
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
@@ -488,7 +493,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // a wave is decoded by exactly one instantiation: 12 or 32 taps x {24-bit, 32-bit, 64-bit} arithmetic
     const int cls = maxord <= 12 ? 12 : 32;
     const int arith = any_wide ? 2 : any_big ? 1 : 0;
-    if (cls != NT || arith != ARITH) return;
+    if (cls != NT || arith != ARITH) {
+        if (lane == 0) p.class_flags[(cls == 12 ? 0 : 1) + 2 * arith] = 1;
+        return;
+    }
 
     const uint32_t bs_max = wave_max_u32(active ? bs : 0);
     if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; }
