@@ -279,17 +279,32 @@ __device__ inline bool is_side(uint32_t ch_assign, uint32_t c)
     return (ch_assign == 8 && c == 1) || (ch_assign == 9 && c == 0) || (ch_assign == 10 && c == 1);
 }
 
+__device__ inline uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return v;
+}
+
 // -------------------------------------------------------------------- skim --
 
 // One lane per candidate frame r in [r_begin, r_end); C channels.  Records
 // subpos[r*8 + c] for every channel and turns frames that fail to parse into
-// their error status.  The lanes of a wave run a small state machine in
-// lockstep, one step per iteration (a header, a partition parameter, or the
-// length of one Rice code), with a ring refill every 16 steps.
+// their error status.  Subframes 0 .. C-2 are walked one after the other; the
+// last one is checked by its decode lane.
+//
+// The lanes of a wave move through a subframe's residual in step, by sample
+// index, in groups of 16 samples: partition boundaries are multiples of the
+// partition size in every lane, so the lanes reach them together, at group
+// boundaries.  A group in which every lane is inside a Rice partition runs
+// branch-free and speculatively, two codes per 32-bit window when the Rice
+// parameters are small: a lane whose codes did not fit (or whose ring ran dry)
+// is rolled back and walks the group code by code.
 __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, uint64_t in_vecs, CandArrays c,
                                               uint32_t r_begin, uint32_t r_end, uint32_t C)
 {
     __shared__ __align__(16) uint32_t s_ring[4 * kRingWords * 64];
+    constexpr uint32_t G = 16;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *wave_ring = s_ring + (threadIdx.x >> 6) * (kRingWords * 64);
     const uint32_t r = r_begin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,81 +322,147 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
         limit = (a + c.len[r]) * 8;   // first bit after the frame
         br.seek((a + info_hl(info)) * 8);
     }
-    enum { S_HDR, S_PART, S_RICE, S_DONE };
-    uint32_t state = active ? S_HDR : S_DONE;
-    uint32_t ch = 0, order = 0, psamp = 0, parts_left = 0, part_rem = 0, k = 0, pbits = 4, esc = 15;
-    bool first_part = true;
+    bool alive = active;
     int rc = kFrameOK;
     const uint4 *in_vec = reinterpret_cast<const uint4 *>(in);
-
     RingFetch rf;
     rf.clear();
-    ring_round(br, rf, state != S_DONE, in_vec, in_vecs, wave_ring, lane);
-    ring_round(br, rf, state != S_DONE, in_vec, in_vecs, wave_ring, lane);
-    while (__any(state != S_DONE)) {
-        ring_round(br, rf, state != S_DONE, in_vec, in_vecs, wave_ring, lane);
-        for (int step = 0; step < (int)kRoundSteps; ++step) {
-            if (state == S_RICE) {
-                skip_rice(br, k, limit);
-                if (--part_rem == 0) state = S_PART;
-            } else if (state == S_PART) {
-                if (br.pos() > limit) { rc = kFrameTruncated; state = S_DONE; }
-                else if (parts_left == 0) { ++ch; state = S_HDR; }
+
+    for (uint32_t ch = 0; ch + 1 < C; ++ch) {
+        uint32_t order = 0, psamp = 0, parts_left = 0, part_rem = 0, k = 0, pbits = 4, esc = 15;
+        bool first_part = true, escaped = false, rice = false;
+        auto kill = [&](int code) { rc = code; alive = false; rice = false; };
+        // ---- subframe header, warm-up samples, predictor parameters, residual header
+        if (alive) {
+            c.subpos[(uint64_t)r * 8 + ch] = br.pos();
+            SubHdr h;
+            const int hrc = read_subframe_header(br, bps + (is_side(ca, ch) ? 1 : 0), bs, limit, h);
+            if (hrc) kill(hrc);
+            else if (h.kind == 0) br.skip(h.sbps);
+            else if (h.kind == 1) {
+                const uint64_t n = (uint64_t)bs * h.sbps;
+                if (br.pos() + n > limit) kill(kFrameTruncated); else br.skip_long((uint32_t)n);
+            } else {
+                order = h.order;
+                if (br.pos() + (uint64_t)order * h.sbps > limit) kill(kFrameTruncated);
                 else {
-                    --parts_left;
-                    uint32_t cnt = psamp - (first_part ? order : 0);
-                    first_part = false;
-                    k = br.read(pbits);
-                    if (k == esc) {
-                        const uint32_t wd = br.read(5);
-                        const uint64_t n = (uint64_t)cnt * wd;
-                        if (br.pos() + n > limit) { rc = kFrameTruncated; state = S_DONE; }
-                        else br.skip_long((uint32_t)n);
-                        cnt = 0;
+                    if (order) br.skip_long(order * h.sbps);
+                    if (h.lpc) {
+                        const uint32_t pc = br.read(4);
+                        const int32_t shift = br.read_signed(5);
+                        if (pc == 15 || shift < 0) kill(kFrameBadSubframe); else br.skip_long(order * (pc + 1));
                     }
-                    part_rem = cnt;
-                    if (cnt && state != S_DONE) state = S_RICE;
+                    if (alive) {
+                        const uint32_t method = br.read(2);
+                        const uint32_t po = br.read(4);
+                        pbits = method ? 5 : 4; esc = method ? 31 : 15;
+                        psamp = bs >> po;
+                        if (method > 1 || (bs & ((1u << po) - 1)) || psamp < order) kill(kFrameBadSubframe);
+                        else { parts_left = 1u << po; rice = true; }
+                    }
                 }
-            } else if (state == S_HDR) {
-                c.subpos[(uint64_t)r * 8 + ch] = br.pos();
-                if (ch + 1 == C) { state = S_DONE; }   // the last subframe is checked by its decode lane
-                else {
-                    SubHdr h;
-                    rc = read_subframe_header(br, bps + (is_side(ca, ch) ? 1 : 0), bs, limit, h);
-                    if (rc) state = S_DONE;
-                    else if (h.kind == 0) {
-                        br.skip(h.sbps);
-                        if (br.pos() > limit) { rc = kFrameTruncated; state = S_DONE; } else ++ch;
-                    } else if (h.kind == 1) {
-                        const uint64_t n = (uint64_t)bs * h.sbps;
-                        if (br.pos() + n > limit) { rc = kFrameTruncated; state = S_DONE; }
-                        else { br.skip_long((uint32_t)n); ++ch; }
-                    } else {
-                        order = h.order;
-                        if (br.pos() + (uint64_t)order * h.sbps > limit) { rc = kFrameTruncated; state = S_DONE; }
-                        else {
-                            br.skip_long(order * h.sbps);
-                            if (h.lpc) {
-                                const uint32_t pc = br.read(4);
-                                const int32_t shift = br.read_signed(5);
-                                if (pc == 15 || shift < 0) { rc = kFrameBadSubframe; state = S_DONE; }
-                                else br.skip_long(order * (pc + 1));
-                            }
-                            if (state != S_DONE) {
-                                const uint32_t method = br.read(2);
-                                const uint32_t po = br.read(4);
-                                pbits = method ? 5 : 4; esc = method ? 31 : 15;
-                                psamp = bs >> po;
-                                if (method > 1 || (bs & ((1u << po) - 1)) || psamp < order) { rc = kFrameBadSubframe; state = S_DONE; }
-                                else if (br.pos() > limit) { rc = kFrameTruncated; state = S_DONE; }
-                                else { parts_left = 1u << po; part_rem = 0; first_part = true; state = S_PART; }
-                            }
+            }
+            if (alive && br.pos() > limit) kill(kFrameTruncated);
+        }
+        // Opens partitions until one holds a sample.  Escape-coded partitions are skipped over here, in one
+        // move; their samples then pass as groups that read nothing.
+        auto open_partition = [&]() {
+            while (part_rem == 0 && parts_left && rice) {
+                part_rem = psamp - (first_part ? order : 0);
+                first_part = false;
+                --parts_left;
+                k = br.read(pbits);
+                escaped = (k == esc);
+                if (escaped) {
+                    const uint32_t wd = br.read(5);
+                    const uint64_t n = (uint64_t)part_rem * wd;
+                    if (br.pos() + n > limit) kill(kFrameTruncated);
+                    else if (n) br.skip_long((uint32_t)n);
+                }
+                if (rice && br.pos() > limit) kill(kFrameTruncated);
+            }
+            if (part_rem == 0) rice = false;   // no partition left
+        };
+
+        ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+        ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+        const uint32_t bs_max = wave_max_u32(rice ? bs : 0);
+        for (uint32_t n0 = 0; n0 < bs_max; n0 += G) {
+            ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+            if (rice && n0 < bs && br.pos() > limit) kill(kFrameTruncated);
+            if (rice && n0 < bs && part_rem == 0 && n0 >= order) open_partition();
+            const bool on = rice && n0 < bs;
+            const bool aligned = !on || (n0 >= order && n0 + G <= bs && part_rem >= G);
+            bool redo = true;
+            bool run_generic = !__all(aligned);
+            if (!run_generic) {
+                const bool reads = on && !escaped;
+                const uint32_t s_rd = br.rd, s_bit = br.bit, s_hi = br.hi, s_lo = br.lo, s_pf = br.pf;
+                uint32_t longest = 0;
+                bool starved = false;
+                const bool pairs = __all(!reads || k <= 12);
+                if (pairs) {
+                    // two codes per window: the second is read from the window shifted by the first
+#pragma unroll
+                    for (int P = 0; P < (int)G / 2; ++P) {
+                        const uint32_t w = br.peek();
+                        const uint32_t n1 = __clz(w) + 1 + k;
+                        const uint32_t w2 = w << (n1 & 31);
+                        const uint32_t tot = n1 + __clz(w2) + 1 + k;
+                        longest = max(longest, tot);
+                        br.bit += reads ? tot : 0u;
+                        const bool take = br.bit >= 32;
+                        br.hi = take ? br.lo : br.hi;
+                        br.lo = take ? br.pf : br.lo;
+                        br.rd += take ? 1u : 0u;
+                        br.bit &= 31;
+                        br.pf = br.ring[(br.rd & (kRingWords - 1)) * 64];
+                    }
+                } else {
+#pragma unroll
+                    for (int P = 0; P < (int)G; ++P) {
+                        if (P == (int)kRoundSteps) {
+                            starved = starved || (reads && br.rd >= br.fill);
+                            ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+                        }
+                        const uint32_t nb = __clz(br.peek()) + 1 + k;
+                        longest = max(longest, nb);
+                        br.bit += reads ? nb : 0u;
+                        const bool take = br.bit >= 32;
+                        br.hi = take ? br.lo : br.hi;
+                        br.lo = take ? br.pf : br.lo;
+                        br.rd += take ? 1u : 0u;
+                        br.bit &= 31;
+                        br.pf = br.ring[(br.rd & (kRingWords - 1)) * 64];
+                    }
+                }
+                starved = starved || (reads && br.rd >= br.fill);
+                redo = reads && (starved || longest > 32);
+                if (on && !redo) part_rem -= G;
+                if (redo) {
+                    br.rd = s_rd; br.bit = s_bit; br.hi = s_hi; br.lo = s_lo; br.pf = s_pf;
+                    if (!pairs) {   // a refill round acted on the speculative read position: forget the ring
+                        br.fill = s_rd & ~(kUnitWords - 1);
+                        br.issued = kNoFill;
+                    }
+                }
+                run_generic = __any(redo);
+            }
+            if (run_generic) {
+                for (uint32_t n = n0; n < n0 + G; ++n) {
+                    if (n - n0 == kRoundSteps) ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+                    if (redo && rice && n >= order && n < bs) {
+                        if (part_rem == 0) open_partition();
+                        if (rice) {
+                            if (!escaped) skip_rice(br, k, limit);
+                            --part_rem;
                         }
                     }
                 }
             }
         }
     }
+    if (alive && C) c.subpos[(uint64_t)r * 8 + (C - 1)] = br.pos();
     if (active && rc) c.status[r] = rc;
 }
 
@@ -399,13 +480,6 @@ struct DecodeParams {
     uint32_t *class_flags; // [6]: set when some wave of the run belongs to that (taps, arithmetic) class
     uint32_t check_flag;   // leave at once when this instantiation's flag is not set
 };
-
-__device__ inline uint32_t wave_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
-    return v;
-}
 
 // Predictor classes: a wave runs in the smallest class that holds the largest
 // order among its lanes.  U = history ring size and unroll factor, NT = taps.
