@@ -106,7 +106,7 @@ struct BitReader {
     __device__ inline uint32_t pos() const { return (rd - 2) * 32 + bit; }
     __device__ inline uint32_t peek() const
     {
-        return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (32 - bit));
+        return (uint32_t)((((((uint64_t)hi) << 32) | lo) << bit) >> 32);
     }
     // General skip (n <= 32): checks that the ring holds the word it moves to.
     __device__ inline void skip(uint32_t n)
@@ -210,6 +210,15 @@ __device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
     int32_t r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+
+// Leading zeros of w; 0xFFFFFFFF when w is zero (the hardware's answer, without the clamp to 32 that
+// __clz adds).  The speculative loops keep the largest count they saw and test it once per group.
+__device__ inline uint32_t lead_zeros_raw(uint32_t w)
+{
+    uint32_t q;
+    asm("v_ffbh_u32 %0, %1" : "=v"(q) : "v"(w));
+    return q;
 }
 
 __device__ inline int32_t unzigzag(uint32_t u) { return (int32_t)((u >> 1) ^ (0u - (u & 1))); }
@@ -485,21 +494,27 @@ struct DecodeParams {
 // order among its lanes.  U = history ring size and unroll factor, NT = taps.
 __host__ __device__ constexpr int class_unroll(int nt) { return nt <= 16 ? 16 : 32; }
 
-constexpr uint32_t kTile = 32;   // samples staged in LDS between write-outs
+constexpr uint32_t kTile = 32;    // samples staged in LDS between write-outs (packed tile)
+constexpr uint32_t kTile16 = 16;  // samples staged per write-out in the 16-bit stereo kernels (raw tile)
+constexpr uint32_t kRawStride = 66;   // words per sample column of the raw tile: 64 lanes + 2, so that the
+                                      // write-out's 8-byte reads (16 lanes, one frame, 16 columns) cover all banks once
 
-// LDS bytes one wave needs: the sample tile (rows padded by 4 bytes so that rows
-// start on different banks) plus per-frame destination and block size.
-__host__ __device__ inline uint32_t decode_wave_lds(uint32_t C, uint32_t B)
+// LDS bytes one wave needs: the refill ring, the sample tile and per-frame destination, block size, mode.
+// Packed tile (general kernels): rows of kTile samples x C channels x B bytes per frame, padded by 4 bytes so
+// that rows start on different banks.  Raw tile (16-bit stereo): one 32-bit word per lane and sample.
+__host__ __device__ inline uint32_t decode_wave_lds(uint32_t C, uint32_t B, bool stereo16)
 {
     const uint32_t F = 64 / C, row_stride = kTile * C * B + 4;
-    return kRingBytesPerWave + ((F * row_stride + 15) & ~15u) + F * 16;
+    const uint32_t tile = stereo16 ? kTile16 * kRawStride * 4 : ((F * row_stride + 15) & ~15u);
+    return kRingBytesPerWave + tile + F * 16;
 }
 
 // One lane per (frame, channel); a wave holds floor(64 / C) frames.
 // NT: predictor taps evaluated per sample (12 or 32).
 // ARITH: 0 = 24-bit multiplies (every subframe of the wave is at most 24 bits wide),
 //        1 = 32-bit multiplies, 2 = 64-bit sums.
-// STEREO16: C == 2 and B == 2, the pair of lanes writes one packed word per sample.
+// STEREO16: C == 2 and B == 2.  Lanes stage their samples as coded; decorrelation and packing to
+//           one 32-bit word per sample pair happen in the write-out, once per output word.
 //
 // Samples are processed in groups of U.  A group in which every lane is in the
 // middle of a Rice partition (or constant / finished) runs the unrolled fast
@@ -512,6 +527,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int U = class_unroll(NT);
+    constexpr uint32_t kT = STEREO16 ? kTile16 : kTile;
     // The instantiation launched first runs every wave and flags the classes its waves turn out to belong
     // to; the launches that follow are over in microseconds when no wave is theirs.
     if (p.check_flag && p.class_flags[(NT == 12 ? 0 : 1) + 2 * ARITH] == 0) return;
@@ -520,11 +536,14 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
     const uint32_t F = 64 / C;
     const uint32_t row_stride = kTile * CB + 4;
-    const uint32_t wave_bytes = decode_wave_lds(C, B);
+    const uint32_t wave_bytes = decode_wave_lds(C, B, STEREO16);
+    const uint32_t tile_bytes = STEREO16 ? kTile16 * kRawStride * 4 : ((F * row_stride + 15) & ~15u);
     uint32_t *wave_ring = reinterpret_cast<uint32_t *>(smem + wave_in_block * wave_bytes);
     uint8_t *tile = smem + wave_in_block * wave_bytes + kRingBytesPerWave;
-    uint64_t *s_dst = reinterpret_cast<uint64_t *>(tile + ((F * row_stride + 15) & ~15u));
+    uint32_t *tile_raw = reinterpret_cast<uint32_t *>(tile);
+    uint64_t *s_dst = reinterpret_cast<uint64_t *>(tile + tile_bytes);
     uint32_t *s_bs = reinterpret_cast<uint32_t *>(s_dst + F);
+    uint32_t *s_mode = s_bs + F;
 
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const uint32_t fl = lane / C, ch = lane - fl * C;
@@ -573,10 +592,17 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     }
 
     const uint32_t bs_max = wave_max_u32(active ? bs : 0);
-    if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; }
+    if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; s_mode[fl] = ca; }
     // whole-dword write-out needs every frame's destination 4-byte aligned
     const bool dwords = (CB & 3) == 0 && !__any(active && (dst & 3));
     __builtin_amdgcn_wave_barrier();
+    // 16-bit stereo write-out: this lane packs sample column (lane & 15) of frames 4*it + (lane >> 4);
+    // their channel assignments, 4 bits each
+    uint32_t modes = 0;
+    if (STEREO16) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) modes |= (s_mode[it * 4 + (lane >> 4)] & 15u) << (4 * it);
+    }
 
     // ---- per-lane decoder state --------------------------------------------------------
     int32_t coef[NT];
@@ -635,29 +661,24 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             if (br.pos() > limit) status = kFrameTruncated;
         }
     };
-    // Stereo decorrelation + staging of one sample into the LDS tile.  `col` = sample index inside the tile.
-    // Samples that do not fit the subframe's width mark the frame invalid (ovf).
+    // Staging of one sample into the LDS tile; `col` = sample index inside the tile.  Samples that do not
+    // fit the subframe's width mark the frame invalid: v + 2^(sbits-1) has no bit above sbits-1 exactly
+    // when v is in range, and the OR of those sums is tested once at the end.
     const uint32_t sbits = h.sbps ? h.sbps : 32u;
+    const uint32_t half = 1u << (sbits - 1);
     const bool is_ls = ca == 8, is_sr = ca == 9, is_ms = ca == 10;
     uint32_t ovf = 0;
     auto emit = [&](int32_t v, bool live, uint32_t col, auto always) {
         constexpr bool ALWAYS = decltype(always)::value;   // fast groups store from every lane: a dead lane's row is never written out
-        ovf |= (uint32_t)(v ^ __builtin_amdgcn_sbfe(v, 0, sbits));
+        ovf |= (uint32_t)v + half;
         uint32_t o = (uint32_t)v << h.wasted;
         if (STEREO16) {
-            // exchange with the other lane of the pair (quad_perm [1,0,3,2])
-            const uint32_t q = (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
-            const uint32_t a = ch == 0 ? o : q, b = ch == 0 ? q : o;   // channel 0 / channel 1 as coded
-            const uint32_t mm = (a << 1) | (b & 1);
-            const uint32_t mL = (uint32_t)((int32_t)(mm + b) >> 1), mR = (uint32_t)((int32_t)(mm - b) >> 1);
-            const uint32_t L = is_ms ? mL : is_sr ? a + b : a;
-            const uint32_t R = is_ms ? mR : is_ls ? a - b : b;
-            if (ALWAYS || (live && ch == 0))   // both lanes of a pair hold the same word
-                *reinterpret_cast<uint32_t *>(tile + fl * row_stride + col * 4) = (L & 0xFFFFu) | (R << 16);
+            if (ALWAYS || live) tile_raw[col * kRawStride + lane] = o;
         } else {
             if (C == 2) {
+                // exchange with the other lane of the pair (quad_perm [1,0,3,2])
                 const uint32_t q = (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
-                const uint32_t a = ch == 0 ? o : q, b = ch == 0 ? q : o;
+                const uint32_t a = ch == 0 ? o : q, b = ch == 0 ? q : o;   // channel 0 / channel 1 as coded
                 const uint32_t mm = (a << 1) | (b & 1);
                 const uint32_t mL = (uint32_t)((int32_t)(mm + b) >> 1), mR = (uint32_t)((int32_t)(mm - b) >> 1);
                 const uint32_t L = is_ms ? mL : is_sr ? a + b : a;
@@ -708,26 +729,50 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             return sum >> shift;
         }
     };
-    // Writes the staged samples [n0, n0 + kTile) of every frame of this wave as runs of up to kTile*C*B bytes.
-    auto flush = [&](uint32_t n0) {
+    // Write-out of the staged samples [t0, t0 + kT) of every frame of this wave.
+    auto flush = [&](uint32_t t0) {
         __builtin_amdgcn_wave_barrier();
-        const uint32_t row_bytes = kTile * CB;
-        if (dwords) {
-            const uint32_t row_words = row_bytes >> 2;
-            for (uint32_t i = lane; i < F * row_words; i += 64) {
-                const uint32_t f = i / row_words, col = i - f * row_words;
-                const uint32_t fbs = s_bs[f];
-                const uint32_t valid = fbs > n0 ? min(kTile, fbs - n0) * CB : 0;
-                if (col * 4 < valid)
-                    *reinterpret_cast<uint32_t *>(s_dst[f] + (uint64_t)n0 * CB + col * 4) =
-                        *reinterpret_cast<const uint32_t *>(tile + f * row_stride + col * 4);
+        if (STEREO16) {
+            // one output word (left | right << 16) per lane and step: 16 lanes write 64 contiguous bytes of one frame
+            const uint32_t col = lane & 15;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const uint32_t f = it * 4 + (lane >> 4);
+                const uint2 ab = *reinterpret_cast<const uint2 *>(tile_raw + col * kRawStride + 2 * f);
+                const uint32_t a = ab.x, b = ab.y, m = (modes >> (4 * it)) & 15u;
+                const uint32_t mm = (a << 1) | (b & 1);
+                const uint32_t mL = (uint32_t)((int32_t)(mm + b) >> 1), mR = (uint32_t)((int32_t)(mm - b) >> 1);
+                const uint32_t L = m == 10 ? mL : m == 9 ? a + b : a;
+                const uint32_t R = m == 10 ? mR : m == 8 ? a - b : b;
+                const uint32_t word = (L & 0xFFFFu) | (R << 16);
+                if (t0 + col < s_bs[f]) {
+                    const uint64_t at = s_dst[f] + (uint64_t)(t0 + col) * 4;
+                    if (dwords) *reinterpret_cast<uint32_t *>(at) = word;
+                    else {
+                        uint8_t *q = reinterpret_cast<uint8_t *>(at);
+                        q[0] = (uint8_t)word; q[1] = (uint8_t)(word >> 8); q[2] = (uint8_t)(word >> 16); q[3] = (uint8_t)(word >> 24);
+                    }
+                }
             }
         } else {
-            for (uint32_t i = lane; i < F * row_bytes; i += 64) {
-                const uint32_t f = i / row_bytes, col = i - f * row_bytes;
-                const uint32_t fbs = s_bs[f];
-                const uint32_t valid = fbs > n0 ? min(kTile, fbs - n0) * CB : 0;
-                if (col < valid) *reinterpret_cast<uint8_t *>(s_dst[f] + (uint64_t)n0 * CB + col) = tile[f * row_stride + col];
+            const uint32_t row_bytes = kTile * CB;
+            if (dwords) {
+                const uint32_t row_words = row_bytes >> 2;
+                for (uint32_t i = lane; i < F * row_words; i += 64) {
+                    const uint32_t f = i / row_words, col = i - f * row_words;
+                    const uint32_t fbs = s_bs[f];
+                    const uint32_t valid = fbs > t0 ? min(kTile, fbs - t0) * CB : 0;
+                    if (col * 4 < valid)
+                        *reinterpret_cast<uint32_t *>(s_dst[f] + (uint64_t)t0 * CB + col * 4) =
+                            *reinterpret_cast<const uint32_t *>(tile + f * row_stride + col * 4);
+                }
+            } else {
+                for (uint32_t i = lane; i < F * row_bytes; i += 64) {
+                    const uint32_t f = i / row_bytes, col = i - f * row_bytes;
+                    const uint32_t fbs = s_bs[f];
+                    const uint32_t valid = fbs > t0 ? min(kTile, fbs - t0) * CB : 0;
+                    if (col < valid) *reinterpret_cast<uint8_t *>(s_dst[f] + (uint64_t)t0 * CB + col) = tile[f * row_stride + col];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -743,7 +788,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     const bool trailing = __any(active && status == kFrameOK && kind == 2 && order >= bs);
     const uint32_t n_end = ((bs_max + U - 1) / U) * U + (trailing ? U : 0);
     for (uint32_t n0 = 0; n0 < n_end; n0 += U) {
-        const uint32_t tile_n0 = n0 & ~(kTile - 1);
+        const uint32_t col0 = n0 & (kT - 1);   // the group's first column in its tile
         ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
         const bool on = active && status == kFrameOK && n0 < bs;
         if (on && kind == 2 && started && part_rem == 0) next_partition();
@@ -762,29 +807,31 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
         if (!run_generic) {
             // ---- fast group: U Rice codes per lane, speculatively and without branches ------
             // Every code is assumed to fit the 32-bit window and every word to be in the ring.
-            // A lane for which that fails (longest code seen > 32 bits, or the reader ran past
+            // A lane for which that fails (a code longer than 32 bits, or the reader ran past
             // `fill`) has produced garbage: its state is rolled back to the start of the group
-            // and the generic body redoes the group for it.
+            // and the generic body redoes the group for it.  Lanes that have no residual to
+            // read (constant subframes, blocks that have ended) let their reader run along and
+            // get it back afterwards.
             const uint32_t s_rd = br.rd, s_bit = br.bit, s_hi = br.hi, s_lo = br.lo, s_pf = br.pf, s_ovf = ovf;
             int32_t s_hist[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) s_hist[j] = ring[U - 1 - j];
-            uint32_t longest = 0;
+            uint32_t longest_q = 0;
             bool starved = false;
 #pragma unroll
             for (int P = 0; P < U; ++P) {
                 if (P && P % kRoundSteps == 0) {
-                    starved = starved || (rice_on && br.rd >= br.fill);
-                    ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
+                    starved = starved || br.rd >= br.fill;
+                    ring_round(br, rf, rice_on, in_vec, p.in_vecs, wave_ring, lane);
                 }
                 // Rice code: unary part = leading zeros of the window, then k low bits
                 const uint32_t w = br.peek();
-                const uint32_t q = __clz(w);
+                const uint32_t q = lead_zeros_raw(w);
+                longest_q = max(longest_q, q);
                 const uint32_t nb = q + 1 + k;
-                longest = max(longest, nb);
                 const uint32_t low = __builtin_amdgcn_ubfe(w, 32 - nb, k);
                 const int32_t res = unzigzag((q << k) | low);
-                br.bit += rice_on ? nb : 0u;
+                br.bit += nb;
                 const bool take = br.bit >= 32;
                 br.hi = take ? br.lo : br.hi;
                 br.lo = take ? br.pf : br.lo;
@@ -794,24 +841,28 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 const int32_t pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
                 const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
                 ring[P] = v;
-                emit(v, on, n0 + P - tile_n0, std::true_type{});
+                emit(v, on, STEREO16 ? ((uint32_t)P & (kT - 1)) : col0 + (uint32_t)P, std::true_type{});
+                if (STEREO16 && U > (int)kTile16 && P == (int)kTile16 - 1) flush(n0);
             }
-            starved = starved || (rice_on && br.rd >= br.fill);
+            starved = starved || br.rd >= br.fill;
 #ifdef FLACGPU_DEBUG_FORCE_REDO
             redo = rice_on;
 #else
-            redo = rice_on && (starved || longest > 32);
+            redo = rice_on && (starved || longest_q > 31 - k);   // q + 1 + k > 32; a zero window counts as 2^32 - 1 zeros
 #endif
-            // the two lanes of a stereo pair exchange samples: they are redone together
-            // (the exchange must run in every lane, so it is not the right-hand side of a short-circuit ||)
-            if (C == 2) {
+            if (C == 2 && !STEREO16) {
+                // the two lanes of a stereo pair exchange samples: they are redone together
+                // (the exchange must run in every lane, so it is not the right-hand side of a short-circuit ||)
                 const int partner = __builtin_amdgcn_mov_dpp((int)redo, 0xB1, 0xF, 0xF, true);
                 redo = redo | (partner != 0);
             }
             if (rice_on && !redo) part_rem -= U;
             run_generic = __any(redo);
+            if (redo || !rice_on) {
+                br.rd = s_rd; br.bit = s_bit; br.hi = s_hi; br.lo = s_lo; br.pf = s_pf;
+            }
             if (redo) {
-                br.rd = s_rd; br.bit = s_bit; br.hi = s_hi; br.lo = s_lo; br.pf = s_pf; ovf = s_ovf;
+                ovf = s_ovf;
                 // the refill round inside the group acted on the speculative read position: forget the
                 // ring (words come from global memory until the next rounds have refilled it)
                 br.fill = s_rd & ~(kUnitWords - 1);
@@ -828,6 +879,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             for (uint32_t n = n0; n < n0 + U; ++n) {
                 if (n != n0 && ((n - n0) % kRoundSteps) == 0)
                     ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
+                if (STEREO16 && U > (int)kTile16 && n - n0 == kTile16) flush(n0);
                 const bool ok = active && status == kFrameOK && redo;
                 const bool live = ok && n < bs;
                 if (ok && kind == 2 && !started && n >= order) {
@@ -859,17 +911,20 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                     for (int j = NT - 1; j > 0; --j) hist[j] = hist[j - 1];
                     hist[0] = v;
                 }
-                emit(v, live && status == kFrameOK, n - tile_n0, std::false_type{});
+                emit(v, live && status == kFrameOK, n & (kT - 1), std::false_type{});
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) ring[U - 1 - j] = hist[j];
         }
         const uint32_t done = n0 + U;
-        if ((done & (kTile - 1)) == 0 || done >= n_end) { if (tile_n0 < bs_max) flush(tile_n0); }
+        if ((done & (kT - 1)) == 0 || done >= n_end) {
+            const uint32_t t0 = (done - 1) & ~(kT - 1);   // tile that holds the group's last sample
+            if (t0 < bs_max) flush(t0);
+        }
     }
 
     if (active) {
-        if (status == kFrameOK && ovf && sbits < 32) status = kFrameBadSubframe;   // a sample wider than its subframe
+        if (status == kFrameOK && sbits < 32 && (ovf >> sbits)) status = kFrameBadSubframe;   // a sample wider than its subframe
         if (status == kFrameOK) {
             // a subframe ends where the next begins; the last one ends at the CRC-16, byte aligned
             const uint32_t end = br.pos();
