@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
         br.init(p.in, p.in_vecs, goff, wave_ring + lane);
         br.seek(p.c.subpos[(uint64_t)r * 8 + ch]);
         const uint64_t first = info_var(info) ? p.c.num[r] : p.c.num[r] * (uint64_t)s.max_bs;
-        dst = reinterpret_cast<uint64_t>(p.out) + s.out_off + first * CB;
+        dst = s.out_off + first * CB;   // from p.out
         const int rc = read_subframe_header(br, info_bps(info) + (is_side(ca, ch) ? 1 : 0), bs, limit, h);
         if (rc) { status = rc; h.kind = 0; h.order = 0; }
     }
@@ -594,14 +594,23 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     const uint32_t bs_max = wave_max_u32(active ? bs : 0);
     if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; s_mode[fl] = ca; }
     // whole-dword write-out needs every frame's destination 4-byte aligned
-    const bool dwords = (CB & 3) == 0 && !__any(active && (dst & 3));
+    const bool dwords = (CB & 3) == 0 && !__any(active && ((reinterpret_cast<uint64_t>(p.out) + dst) & 3));
     __builtin_amdgcn_wave_barrier();
     // 16-bit stereo write-out: this lane packs sample column (lane & 15) of frames 4*it + (lane >> 4);
     // their channel assignments, 4 bits each
+    // and where they go (offset of this lane's column from p.out) and how long they are
     uint32_t modes = 0;
+    uint64_t fdst[STEREO16 ? 8 : 1];
+    uint32_t fbs[STEREO16 ? 8 : 1];
+    fdst[0] = 0; fbs[0] = 0;
     if (STEREO16) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) modes |= (s_mode[it * 4 + (lane >> 4)] & 15u) << (4 * it);
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t f = it * 4 + (lane >> 4);
+            modes |= (s_mode[f] & 15u) << (4 * it);
+            fdst[it] = s_dst[f] + (lane & 15) * 4;
+            fbs[it] = s_bs[f];
+        }
     }
 
     // ---- per-lane decoder state --------------------------------------------------------
@@ -735,23 +744,21 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
         if (STEREO16) {
             // one output word (left | right << 16) per lane and step: 16 lanes write 64 contiguous bytes of one frame
             const uint32_t col = lane & 15;
+            uint2 ab[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                ab[it] = *reinterpret_cast<const uint2 *>(tile_raw + col * kRawStride + 2 * (it * 4 + (lane >> 4)));
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const uint32_t f = it * 4 + (lane >> 4);
-                const uint2 ab = *reinterpret_cast<const uint2 *>(tile_raw + col * kRawStride + 2 * f);
-                const uint32_t a = ab.x, b = ab.y, m = (modes >> (4 * it)) & 15u;
-                const uint32_t mm = (a << 1) | (b & 1);
-                const uint32_t mL = (uint32_t)((int32_t)(mm + b) >> 1), mR = (uint32_t)((int32_t)(mm - b) >> 1);
-                const uint32_t L = m == 10 ? mL : m == 9 ? a + b : a;
-                const uint32_t R = m == 10 ? mR : m == 8 ? a - b : b;
+                const uint32_t a = ab[it].x, b = ab[it].y, m = (modes >> (4 * it)) & 15u;
+                // mid/side: left = mid + ceil(side / 2), right = mid - floor(side / 2)
+                const uint32_t L = m == 10 ? a + (uint32_t)(((int32_t)b + 1) >> 1) : m == 9 ? a + b : a;
+                const uint32_t R = m == 10 ? a - (uint32_t)((int32_t)b >> 1) : m == 8 ? a - b : b;
                 const uint32_t word = (L & 0xFFFFu) | (R << 16);
-                if (t0 + col < s_bs[f]) {
-                    const uint64_t at = s_dst[f] + (uint64_t)(t0 + col) * 4;
+                if (t0 + col < fbs[it]) {
+                    uint8_t *at = p.out + fdst[it] + (uint64_t)t0 * 4;
                     if (dwords) *reinterpret_cast<uint32_t *>(at) = word;
-                    else {
-                        uint8_t *q = reinterpret_cast<uint8_t *>(at);
-                        q[0] = (uint8_t)word; q[1] = (uint8_t)(word >> 8); q[2] = (uint8_t)(word >> 16); q[3] = (uint8_t)(word >> 24);
-                    }
+                    else { at[0] = (uint8_t)word; at[1] = (uint8_t)(word >> 8); at[2] = (uint8_t)(word >> 16); at[3] = (uint8_t)(word >> 24); }
                 }
             }
         } else {
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                     const uint32_t fbs = s_bs[f];
                     const uint32_t valid = fbs > t0 ? min(kTile, fbs - t0) * CB : 0;
                     if (col * 4 < valid)
-                        *reinterpret_cast<uint32_t *>(s_dst[f] + (uint64_t)t0 * CB + col * 4) =
+                        *reinterpret_cast<uint32_t *>(p.out + s_dst[f] + (uint64_t)t0 * CB + col * 4) =
                             *reinterpret_cast<const uint32_t *>(tile + f * row_stride + col * 4);
                 }
             } else {
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                     const uint32_t f = i / row_bytes, col = i - f * row_bytes;
                     const uint32_t fbs = s_bs[f];
                     const uint32_t valid = fbs > t0 ? min(kTile, fbs - t0) * CB : 0;
-                    if (col < valid) *reinterpret_cast<uint8_t *>(s_dst[f] + (uint64_t)t0 * CB + col) = tile[f * row_stride + col];
+                    if (col < valid) p.out[s_dst[f] + (uint64_t)t0 * CB + col] = tile[f * row_stride + col];
                 }
             }
         }
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 // Rice code: unary part = leading zeros of the window, then k low bits
                 const uint32_t w = br.peek();
                 const uint32_t q = lead_zeros_raw(w);
-                longest_q = max(longest_q, q);
+                longest_q |= q;
                 const uint32_t nb = q + 1 + k;
                 const uint32_t low = __builtin_amdgcn_ubfe(w, 32 - nb, k);
                 const int32_t res = unzigzag((q << k) | low);
@@ -848,7 +855,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 #ifdef FLACGPU_DEBUG_FORCE_REDO
             redo = rice_on;
 #else
-            redo = rice_on && (starved || longest_q > 31 - k);   // q + 1 + k > 32; a zero window counts as 2^32 - 1 zeros
+            // q + 1 + k > 32 for some code?  The OR of the counts is at least their maximum (a zero window counts
+            // as 2^32 - 1 zeros), so the test never misses one; it is wrong the safe way now and then.
+            redo = rice_on && (starved || longest_q > 31 - k);
 #endif
             if (C == 2 && !STEREO16) {
                 // the two lanes of a stereo pair exchange samples: they are redone together
