@@ -37,34 +37,32 @@ namespace flacgpu {
 // 32 streams x 32 bytes as whole sectors.  A refill is issued one round (8 decode
 // steps) before it is written to the ring, so its latency overlaps decoding.
 constexpr uint32_t kRingWords = 32;   // ring capacity per lane, in 32-bit words
+constexpr uint32_t kRingSlots = 33;   // slot 32 repeats slot 0, so that words w and w + 1 are always one two-word read
 constexpr uint32_t kUnitWords = 8;    // refill granule: 32 bytes
 constexpr uint32_t kRoundSteps = 8;   // decode steps (of at most 32 bits) between refill rounds
-constexpr uint32_t kRingBytesPerWave = kRingWords * 64 * 4;
+constexpr uint32_t kRingBytesPerWave = kRingSlots * 64 * 4;
 constexpr uint32_t kNoFill = 0xFFFFFFFFu;
 
-// MSB-first reader over one lane's bitstream.  Positions are bits from the
-// 64-byte-aligned address at or before the frame's first byte.  Ring word w of
-// the lane sits at ring[(w % kRingWords) * 64] (ring already points at the
-// lane's column), stored big-endian-corrected; the ring holds words
-// [fill - kRingWords, fill).  A word the ring does not hold is read from global
-// memory directly (after a seek, or when a lane outruns the refill schedule).
-// Reads never go past the end of the input buffer (a lane that runs off the end of the
-// batch sees zeros or a repeat of the last 16 bytes, and stops at its frame's bit limit).
+// MSB-first reader over one lane's bitstream.  Its whole state is a bit position P, counted from the
+// 64-byte-aligned address at or before the frame's first byte.  Stream word w of the lane sits at
+// ring[(w % kRingWords) * 64] (ring already points at the lane's column), byte order corrected; the ring
+// holds words [fill - kRingWords, fill).  A word the ring does not hold is read from global memory
+// directly (after a seek, or when a lane outruns the refill schedule).  Reads never go past the end of the
+// input buffer (a lane that runs off the end of the batch sees zeros or a repeat of the last 16 bytes, and
+// stops at its frame's bit limit).
 struct BitReader {
     const uint32_t *gbase;   // global words from the aligned base
     uint32_t nwords;         // words readable from gbase
     uint32_t *ring;
     uint64_t gvec;           // vector (16-byte) index of gbase in the input buffer
-    uint32_t rd;             // index of the word held in `pf`
     uint32_t fill;
     uint32_t issued;         // value of `fill` when a refill was last issued and not yet written, or kNoFill
-    uint32_t bit;            // bits of `hi` already consumed (0..31)
-    uint32_t hi, lo, pf;     // words rd-2, rd-1, rd
+    uint32_t P;              // bit position
 
-    // Direct read of stream word w.  Only cold paths use it (a repositioned reader, a lane that outran
-    // its ring).  The load and its wait are one asm statement on purpose: a compiler-visible load in a
-    // rarely taken branch makes hipcc wait for ALL outstanding memory operations wherever the paths
-    // join, i.e. once per sample in the hot loop, which would serialise the refill prefetches.
+    // Direct read of stream word w.  Only cold paths use it.  The load and its wait are one asm statement
+    // on purpose: a compiler-visible load in a rarely taken branch makes hipcc wait for ALL outstanding
+    // memory operations wherever the paths join, i.e. once per sample in the hot loop, which would
+    // serialise the refill prefetches.
     __device__ inline uint32_t gload(uint32_t w) const
     {
         if (w >= nwords) return 0u;
@@ -73,7 +71,7 @@ struct BitReader {
         asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
         return __builtin_bswap32(v);
     }
-    __device__ inline uint32_t fetch(uint32_t w) const
+    __device__ inline uint32_t word(uint32_t w) const
     {
         if (w < fill) return ring[(w & (kRingWords - 1)) * 64];
         return gload(w);
@@ -85,46 +83,52 @@ struct BitReader {
         gvec = b >> 4;
         nwords = (uint32_t)min((in_vecs - gvec) * 4, (uint64_t)0xFFFFFFFFu);
         ring = lane_ring;
-        rd = fill = bit = hi = lo = pf = 0;
+        fill = P = 0;
         issued = kNoFill;
     }
     __device__ inline void null(uint32_t *lane_ring)
     {
         gbase = nullptr; nwords = 0; ring = lane_ring; gvec = 0;
-        rd = fill = bit = hi = lo = pf = 0;
+        fill = P = 0;
         issued = kNoFill;
     }
     __device__ inline void seek(uint32_t bitpos)
     {
-        const uint32_t w = bitpos >> 5;
-        bit = bitpos & 31;
-        fill = w & ~(kUnitWords - 1);   // ring restarts at this unit; until it is refilled, words come from global memory
+        P = bitpos;
+        fill = (P >> 5) & ~(kUnitWords - 1);   // ring restarts at this unit; until it is refilled, words come from global memory
         issued = kNoFill;
-        hi = gload(w); lo = gload(w + 1); pf = gload(w + 2);
-        rd = w + 2;
     }
-    __device__ inline uint32_t pos() const { return (rd - 2) * 32 + bit; }
+    __device__ inline uint32_t pos() const { return P; }
+    // The 32 bits at P when both words are known to be in the ring (the speculative loops, which test
+    // `starved` afterwards instead).
+    __device__ inline uint32_t peek_ring() const
+    {
+        const uint32_t *q = ring + ((P >> 5) & (kRingWords - 1)) * 64;
+        uint2 t;              // the later word first: it is the low half of the 64-bit window
+        t.x = q[64];
+        t.y = q[0];
+        const uint64_t win = (((uint64_t)t.y) << 32) | t.x;
+        return (uint32_t)((win << (P & 31)) >> 32);
+    }
+    __device__ inline bool starved() const { return (P >> 5) + 1 >= fill; }
     __device__ inline uint32_t peek() const
     {
-        return (uint32_t)((((((uint64_t)hi) << 32) | lo) << bit) >> 32);
+        const uint32_t w = P >> 5;
+        const uint64_t win = (((uint64_t)word(w)) << 32) | word(w + 1);
+        return (uint32_t)((win << (P & 31)) >> 32);
     }
-    // General skip (n <= 32): checks that the ring holds the word it moves to.
-    __device__ inline void skip(uint32_t n)
-    {
-        bit += n;
-        if (bit >= 32) { bit -= 32; hi = lo; lo = pf; ++rd; pf = fetch(rd); }
-    }
-    __device__ inline void skip_long(uint32_t n) { seek(pos() + n); }
+    __device__ inline void skip(uint32_t n) { P += n; }
+    __device__ inline void skip_long(uint32_t n) { seek(P + n); }
     __device__ inline uint32_t read(uint32_t n)   // n <= 32
     {
         const uint32_t v = n ? peek() >> (32 - n) : 0;
-        skip(n);
+        P += n;
         return v;
     }
     __device__ inline int32_t read_signed(uint32_t n)
     {
         const int32_t v = n ? (int32_t)peek() >> (32 - n) : 0;
-        skip(n);
+        P += n;
         return v;
     }
 };
@@ -140,12 +144,12 @@ struct RingFetch {
 // One refill round; all 64 lanes call it together, every kRoundSteps decode steps.
 //   1. commit: the vectors loaded in the previous round are written to their owners'
 //      rings (unless the owner has repositioned its reader since);
-//   2. issue: every lane with 16 or fewer unread words asks for its next 32 bytes; lane
+//   2. issue: every lane with 17 or fewer unread words asks for its next 32 bytes; lane
 //      2i+p loads vector p of lane i's unit (two half-wave passes), to be committed in
 //      the next round.
-// A lane that starts a round with at least 9 unread words has at least 9 at the next
-// round too, whatever it consumes in between (at most 8 words), so the decode loops
-// never wait for memory.  After repositioning, three rounds in a row restore the margin.
+// A lane that starts a round with at least 10 unread words has the two words of its window in
+// the ring until the next round, whatever it consumes in between (at most 8 words), so the
+// decode loops never wait for memory.  After repositioning, three rounds in a row restore the margin.
 __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active, const uint4 *in_vec, uint64_t in_vecs,
                                   uint32_t *wave_ring, uint32_t lane)
 {
@@ -156,21 +160,24 @@ __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active, con
     for (int s = 0; s < 2; ++s) {
         const uint32_t t = 32 * s + (lane >> 1);
         const uint32_t t_fill = (uint32_t)__shfl((int)br.fill, (int)t);
-        if (rf.at[s] != kNoFill && rf.at[s] == t_fill) {
+        if (rf.at[s] == t_fill) {   // a valid `fill` is never kNoFill
             uint32_t *dst = wave_ring + t;
             const uint32_t slot = (t_fill + 4 * p) & (kRingWords - 1);
-            dst[(slot + 0) * 64] = __builtin_bswap32(rf.v[s].x);
+            const uint32_t w0 = __builtin_bswap32(rf.v[s].x);
+            dst[(slot + 0) * 64] = w0;
             dst[(slot + 1) * 64] = __builtin_bswap32(rf.v[s].y);
             dst[(slot + 2) * 64] = __builtin_bswap32(rf.v[s].z);
             dst[(slot + 3) * 64] = __builtin_bswap32(rf.v[s].w);
+            if (slot == 0) dst[kRingWords * 64] = w0;
         }
     }
     if (br.issued != kNoFill && br.issued == br.fill) br.fill += kUnitWords;
     br.issued = kNoFill;
     __builtin_amdgcn_wave_barrier();
     // ---- issue
-    if (active && (int32_t)(br.fill - br.rd) < -(int32_t)kUnitWords + 1) br.fill = br.rd & ~(kUnitWords - 1);
-    const bool want = active && (int32_t)(br.fill - br.rd) <= 16;
+    const uint32_t rdw = br.P >> 5;
+    if (active && (int32_t)(br.fill - rdw) < -(int32_t)kUnitWords + 1) br.fill = rdw & ~(kUnitWords - 1);
+    const bool want = active && (int32_t)(br.fill - rdw) <= 17;
     const uint64_t gv = br.gvec + (br.fill >> 2);
     const uint32_t tag = want ? br.fill : kNoFill;
 #pragma unroll
@@ -312,10 +319,10 @@ __device__ inline uint32_t wave_max_u32(uint32_t v)
 __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, uint64_t in_vecs, CandArrays c,
                                               uint32_t r_begin, uint32_t r_end, uint32_t C)
 {
-    __shared__ __align__(16) uint32_t s_ring[4 * kRingWords * 64];
+    __shared__ __align__(16) uint32_t s_ring[4 * kRingSlots * 64];
     constexpr uint32_t G = 16;
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t *wave_ring = s_ring + (threadIdx.x >> 6) * (kRingWords * 64);
+    uint32_t *wave_ring = s_ring + (threadIdx.x >> 6) * (kRingSlots * 64);
     const uint32_t r = r_begin + blockIdx.x * blockDim.x + threadIdx.x;
     bool active = r < r_end;
     if (active) active = c.status[r] == kFrameOK;
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
             bool run_generic = !__all(aligned);
             if (!run_generic) {
                 const bool reads = on && !escaped;
-                const uint32_t s_rd = br.rd, s_bit = br.bit, s_hi = br.hi, s_lo = br.lo, s_pf = br.pf;
+                const uint32_t s_P = br.P;
                 uint32_t longest = 0;
                 bool starved = false;
                 const bool pairs = __all(!reads || k <= 12);
@@ -414,46 +421,32 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
                     // two codes per window: the second is read from the window shifted by the first
 #pragma unroll
                     for (int P = 0; P < (int)G / 2; ++P) {
-                        const uint32_t w = br.peek();
+                        const uint32_t w = br.peek_ring();
                         const uint32_t n1 = __clz(w) + 1 + k;
                         const uint32_t w2 = w << (n1 & 31);
                         const uint32_t tot = n1 + __clz(w2) + 1 + k;
                         longest = max(longest, tot);
-                        br.bit += reads ? tot : 0u;
-                        const bool take = br.bit >= 32;
-                        br.hi = take ? br.lo : br.hi;
-                        br.lo = take ? br.pf : br.lo;
-                        br.rd += take ? 1u : 0u;
-                        br.bit &= 31;
-                        br.pf = br.ring[(br.rd & (kRingWords - 1)) * 64];
+                        br.P += tot;
                     }
                 } else {
 #pragma unroll
                     for (int P = 0; P < (int)G; ++P) {
                         if (P == (int)kRoundSteps) {
-                            starved = starved || (reads && br.rd >= br.fill);
-                            ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+                            starved = starved || br.starved();
+                            ring_round(br, rf, reads, in_vec, in_vecs, wave_ring, lane);
                         }
-                        const uint32_t nb = __clz(br.peek()) + 1 + k;
+                        const uint32_t nb = __clz(br.peek_ring()) + 1 + k;
                         longest = max(longest, nb);
-                        br.bit += reads ? nb : 0u;
-                        const bool take = br.bit >= 32;
-                        br.hi = take ? br.lo : br.hi;
-                        br.lo = take ? br.pf : br.lo;
-                        br.rd += take ? 1u : 0u;
-                        br.bit &= 31;
-                        br.pf = br.ring[(br.rd & (kRingWords - 1)) * 64];
+                        br.P += nb;
                     }
                 }
-                starved = starved || (reads && br.rd >= br.fill);
+                starved = starved || br.starved();
                 redo = reads && (starved || longest > 32);
                 if (on && !redo) part_rem -= G;
-                if (redo) {
-                    br.rd = s_rd; br.bit = s_bit; br.hi = s_hi; br.lo = s_lo; br.pf = s_pf;
-                    if (!pairs) {   // a refill round acted on the speculative read position: forget the ring
-                        br.fill = s_rd & ~(kUnitWords - 1);
-                        br.issued = kNoFill;
-                    }
+                if (redo || !reads) br.P = s_P;
+                if (redo && !pairs) {   // a refill round acted on the speculative read position: forget the ring
+                    br.fill = (s_P >> 5) & ~(kUnitWords - 1);
+                    br.issued = kNoFill;
                 }
                 run_generic = __any(redo);
             }
@@ -819,7 +812,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             // and the generic body redoes the group for it.  Lanes that have no residual to
             // read (constant subframes, blocks that have ended) let their reader run along and
             // get it back afterwards.
-            const uint32_t s_rd = br.rd, s_bit = br.bit, s_hi = br.hi, s_lo = br.lo, s_pf = br.pf, s_ovf = ovf;
+            const uint32_t s_P = br.P, s_ovf = ovf;
             int32_t s_hist[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) s_hist[j] = ring[U - 1 - j];
@@ -828,30 +821,24 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 #pragma unroll
             for (int P = 0; P < U; ++P) {
                 if (P && P % kRoundSteps == 0) {
-                    starved = starved || br.rd >= br.fill;
+                    starved = starved || br.starved();
                     ring_round(br, rf, rice_on, in_vec, p.in_vecs, wave_ring, lane);
                 }
                 // Rice code: unary part = leading zeros of the window, then k low bits
-                const uint32_t w = br.peek();
+                const uint32_t w = br.peek_ring();
                 const uint32_t q = lead_zeros_raw(w);
                 longest_q |= q;
                 const uint32_t nb = q + 1 + k;
                 const uint32_t low = __builtin_amdgcn_ubfe(w, 32 - nb, k);
                 const int32_t res = unzigzag((q << k) | low);
-                br.bit += nb;
-                const bool take = br.bit >= 32;
-                br.hi = take ? br.lo : br.hi;
-                br.lo = take ? br.pf : br.lo;
-                br.rd += take ? 1u : 0u;
-                br.bit &= 31;
-                br.pf = br.ring[(br.rd & (kRingWords - 1)) * 64];
+                br.P += nb;
                 const int32_t pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
                 const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
                 ring[P] = v;
                 emit(v, on, STEREO16 ? ((uint32_t)P & (kT - 1)) : col0 + (uint32_t)P, std::true_type{});
                 if (STEREO16 && U > (int)kTile16 && P == (int)kTile16 - 1) flush(n0);
             }
-            starved = starved || br.rd >= br.fill;
+            starved = starved || br.starved();
 #ifdef FLACGPU_DEBUG_FORCE_REDO
             redo = rice_on;
 #else
@@ -867,14 +854,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             }
             if (rice_on && !redo) part_rem -= U;
             run_generic = __any(redo);
-            if (redo || !rice_on) {
-                br.rd = s_rd; br.bit = s_bit; br.hi = s_hi; br.lo = s_lo; br.pf = s_pf;
-            }
+            if (redo || !rice_on) br.P = s_P;
             if (redo) {
                 ovf = s_ovf;
                 // the refill round inside the group acted on the speculative read position: forget the
                 // ring (words come from global memory until the next rounds have refilled it)
-                br.fill = s_rd & ~(kUnitWords - 1);
+                br.fill = (s_P >> 5) & ~(kUnitWords - 1);
                 br.issued = kNoFill;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) ring[U - 1 - j] = s_hist[j];
