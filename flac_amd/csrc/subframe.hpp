@@ -30,12 +30,11 @@ namespace flacgpu {
 
 // -------------------------------------------------------------- bit reader --
 
-// Every lane walks its own bitstream, so a direct load would touch 64 different
-// cache lines per wave instruction and use 16 bytes of each.  Instead each lane
-// owns a small ring in LDS that the whole wave refills together: two lanes fetch
-// 32 contiguous bytes of one lane's stream (ring_round), so a wave-wide load reads
-// 32 streams x 32 bytes as whole sectors.  A refill is issued one round (8 decode
-// steps) before it is written to the ring, so its latency overlaps decoding.
+// Every lane walks its own bitstream, so a load per code would touch 64 different
+// cache lines per wave instruction and use 4 bytes of each.  Instead each lane
+// owns a small ring in LDS that it refills 32 bytes (one sector) at a time
+// (ring_round).  A refill is issued one round (8 decode steps) before it is
+// written to the ring, so its latency overlaps decoding.
 constexpr uint32_t kRingWords = 32;   // ring capacity per lane, in 32-bit words
 constexpr uint32_t kRingSlots = 33;   // slot 32 repeats slot 0, so that words w and w + 1 are always one two-word read
 constexpr uint32_t kUnitWords = 8;    // refill granule: 32 bytes
@@ -56,7 +55,6 @@ struct BitReader {
     uint32_t *ring;
     uint64_t gvec;           // vector (16-byte) index of gbase in the input buffer
     uint32_t fill;
-    uint32_t issued;         // value of `fill` when a refill was last issued and not yet written, or kNoFill
     uint32_t P;              // bit position
 
     // Direct read of stream word w.  Only cold paths use it.  The load and its wait are one asm statement
@@ -84,19 +82,16 @@ struct BitReader {
         nwords = (uint32_t)min((in_vecs - gvec) * 4, (uint64_t)0xFFFFFFFFu);
         ring = lane_ring;
         fill = P = 0;
-        issued = kNoFill;
     }
     __device__ inline void null(uint32_t *lane_ring)
     {
         gbase = nullptr; nwords = 0; ring = lane_ring; gvec = 0;
         fill = P = 0;
-        issued = kNoFill;
     }
     __device__ inline void seek(uint32_t bitpos)
     {
         P = bitpos;
         fill = (P >> 5) & ~(kUnitWords - 1);   // ring restarts at this unit; until it is refilled, words come from global memory
-        issued = kNoFill;
     }
     __device__ inline uint32_t pos() const { return P; }
     // The 32 bits at P when both words are known to be in the ring (the speculative loops, which test
@@ -133,66 +128,54 @@ struct BitReader {
     }
 };
 
-// What a lane holds, as a helper, between two refill rounds: the vectors it loaded for
-// other lanes' rings and the ring position they belong to.
+// What a lane holds between two refill rounds: the 32 bytes it loaded for its ring and the ring
+// position they belong to.
 struct RingFetch {
     uint4 v[2];
-    uint32_t at[2];   // target's `fill` when the load was issued, or kNoFill
-    __device__ inline void clear() { at[0] = at[1] = kNoFill; v[0] = v[1] = uint4{0u, 0u, 0u, 0u}; }
+    uint32_t at;   // `fill` when the load was issued, or kNoFill
+    __device__ inline void clear() { at = kNoFill; v[0] = v[1] = uint4{0u, 0u, 0u, 0u}; }
 };
 
 // One refill round; all 64 lanes call it together, every kRoundSteps decode steps.
-//   1. commit: the vectors loaded in the previous round are written to their owners'
-//      rings (unless the owner has repositioned its reader since);
-//   2. issue: every lane with 17 or fewer unread words asks for its next 32 bytes; lane
-//      2i+p loads vector p of lane i's unit (two half-wave passes), to be committed in
-//      the next round.
+//   1. commit: the 32 bytes loaded in the previous round are written to the ring (unless
+//      the reader has been repositioned since);
+//   2. issue: a lane with 17 or fewer unread words loads its next 32 bytes, to be
+//      committed in the next round.
 // A lane that starts a round with at least 10 unread words has the two words of its window in
 // the ring until the next round, whatever it consumes in between (at most 8 words), so the
 // decode loops never wait for memory.  After repositioning, three rounds in a row restore the margin.
+// Each lane loads for itself: 64 lanes touch 64 different lines either way, and the two 16-byte
+// loads of a lane fall into one 32-byte sector.
 __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active, const uint4 *in_vec, uint64_t in_vecs,
                                   uint32_t *wave_ring, uint32_t lane)
 {
-    const uint32_t p = lane & 1;
-    __builtin_amdgcn_wave_barrier();
+    (void)wave_ring; (void)lane;
     // ---- commit
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const uint32_t t = 32 * s + (lane >> 1);
-        const uint32_t t_fill = (uint32_t)__shfl((int)br.fill, (int)t);
-        if (rf.at[s] == t_fill) {   // a valid `fill` is never kNoFill
-            uint32_t *dst = wave_ring + t;
-            const uint32_t slot = (t_fill + 4 * p) & (kRingWords - 1);
-            const uint32_t w0 = __builtin_bswap32(rf.v[s].x);
-            dst[(slot + 0) * 64] = w0;
-            dst[(slot + 1) * 64] = __builtin_bswap32(rf.v[s].y);
-            dst[(slot + 2) * 64] = __builtin_bswap32(rf.v[s].z);
-            dst[(slot + 3) * 64] = __builtin_bswap32(rf.v[s].w);
-            if (slot == 0) dst[kRingWords * 64] = w0;
-        }
+    if (rf.at == br.fill) {   // a valid `fill` is never kNoFill
+        const uint32_t slot = br.fill & (kRingWords - 1);   // a multiple of 8
+        uint32_t *dst = br.ring + slot * 64;
+        const uint32_t w0 = __builtin_bswap32(rf.v[0].x);
+        dst[0 * 64] = w0;
+        dst[1 * 64] = __builtin_bswap32(rf.v[0].y);
+        dst[2 * 64] = __builtin_bswap32(rf.v[0].z);
+        dst[3 * 64] = __builtin_bswap32(rf.v[0].w);
+        dst[4 * 64] = __builtin_bswap32(rf.v[1].x);
+        dst[5 * 64] = __builtin_bswap32(rf.v[1].y);
+        dst[6 * 64] = __builtin_bswap32(rf.v[1].z);
+        dst[7 * 64] = __builtin_bswap32(rf.v[1].w);
+        if (slot == 0) br.ring[kRingWords * 64] = w0;
+        br.fill += kUnitWords;
     }
-    if (br.issued != kNoFill && br.issued == br.fill) br.fill += kUnitWords;
-    br.issued = kNoFill;
-    __builtin_amdgcn_wave_barrier();
     // ---- issue
     const uint32_t rdw = br.P >> 5;
     if (active && (int32_t)(br.fill - rdw) < -(int32_t)kUnitWords + 1) br.fill = rdw & ~(kUnitWords - 1);
     const bool want = active && (int32_t)(br.fill - rdw) <= 17;
-    const uint64_t gv = br.gvec + (br.fill >> 2);
-    const uint32_t tag = want ? br.fill : kNoFill;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const uint32_t t = 32 * s + (lane >> 1);
-        rf.at[s] = (uint32_t)__shfl((int)tag, (int)t);
-        const uint64_t t_gv = ((uint64_t)(uint32_t)__shfl((int)(gv >> 32), (int)t) << 32) |
-                              (uint32_t)__shfl((int)(uint32_t)gv, (int)t);
-        // the load is unconditional (a lane with nothing to fetch re-reads vector 0): a branch around
-        // it would make the compiler copy the result, and so wait for it, right here
-        uint64_t v_idx = t_gv + p;
-        v_idx = rf.at[s] == kNoFill ? 0 : (v_idx < in_vecs ? v_idx : in_vecs - 1);   // never past the input
-        rf.v[s] = in_vec[v_idx];
-    }
-    if (want) br.issued = br.fill;
+    rf.at = want ? br.fill : kNoFill;
+    // the loads are unconditional (a lane with nothing to fetch re-reads vector 0): a branch around
+    // them would make the compiler copy the result, and so wait for it, right here
+    const uint64_t v_idx = br.gvec + (br.fill >> 2), v_last = in_vecs - 1;   // never past the input
+    rf.v[0] = in_vec[want ? (v_idx < v_last ? v_idx : v_last) : 0];
+    rf.v[1] = in_vec[want ? (v_idx + 1 < v_last ? v_idx + 1 : v_last) : 0];
 }
 
 // Unary-coded count: zeros up to and including the terminating one are consumed.
@@ -446,7 +429,6 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
                 if (redo || !reads) br.P = s_P;
                 if (redo && !pairs) {   // a refill round acted on the speculative read position: forget the ring
                     br.fill = (s_P >> 5) & ~(kUnitWords - 1);
-                    br.issued = kNoFill;
                 }
                 run_generic = __any(redo);
             }
@@ -860,7 +842,6 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 // the refill round inside the group acted on the speculative read position: forget the
                 // ring (words come from global memory until the next rounds have refilled it)
                 br.fill = (s_P >> 5) & ~(kUnitWords - 1);
-                br.issued = kNoFill;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) ring[U - 1 - j] = s_hist[j];
             }
