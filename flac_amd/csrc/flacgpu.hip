@@ -188,8 +188,7 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     mark(h, EV_COMPACT, st);
     if (n_cand) {
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_cand + 3) / 4, 256 * 8);
-        k_crc16_spans<<<blocks, 256, 0, st>>>(d_in, (const StreamDev *)h->streams.p, c, n_cand,
-                                               (const uint16_t *)h->crc_tables.p);
+        k_crc16_spans<<<blocks, 256, 0, st>>>(d_in, c, n_cand, (const uint16_t *)h->crc_tables.p);
     }
     mark(h, EV_CRC, st);
     if (n_cand) {

@@ -386,6 +386,10 @@ __global__ __launch_bounds__(256) void k_cand_fill(const uint8_t *__restrict__ i
     c.num[r] = h.num;
     c.info[r] = pack_info(h.bs, h.hdrlen, h.ch_assign, h.bps, h.variable);
     c.stream[r] = (uint32_t)(si < 0 ? 0 : si);
+    // the candidate's span: up to the next candidate, or to the end of its stream
+    uint64_t end = s.in_off + s.in_len;
+    if (r + 1 < n_cand) { const uint64_t nx = c.goff[r + 1]; if (nx < end) end = nx; }
+    c.seglen[r] = si < 0 ? 0u : (uint32_t)(end - g);
 }
 
 // cand_begin / cand_end of every stream by binary search over the candidate offsets.
@@ -449,8 +453,9 @@ __device__ inline void crc16_pow_table(uint16_t *pow2)
 //   lanew[l]     (64)        x^(8 * 16 * (63 - l))
 //   remw[r]      (16)        x^(8 * r)
 //   pow2[k]      (32)        x^(8 * 2^k), for gf_xpow8
+//   inv[r]       (16)        x^(-8 * r): x has order 32767 modulo 0x18005 = (x + 1)(x^15 + x + 1)
 constexpr int kCrcPiece = 0, kCrcSkip = 16 * 256, kCrcLane = kCrcSkip + 512, kCrcRem = kCrcLane + 64,
-              kCrcPow2 = kCrcRem + 16, kCrcTableEntries = kCrcPow2 + 32;
+              kCrcPow2 = kCrcRem + 16, kCrcInv = kCrcPow2 + 32, kCrcTableEntries = kCrcInv + 16;
 
 __global__ void k_crc16_build_tables(uint16_t *t)
 {
@@ -469,8 +474,10 @@ __global__ void k_crc16_build_tables(uint16_t *t)
             v = gf_xpow8(16 * (63 - (i - kCrcLane)), s_pow2);
         } else if (i < (uint32_t)kCrcPow2) {
             v = gf_xpow8(i - kCrcRem, s_pow2);
-        } else {
+        } else if (i < (uint32_t)kCrcInv) {
             v = s_pow2[i - kCrcPow2];
+        } else {
+            v = gf_xpow8((32767u - (i - kCrcInv)) % 32767u, s_pow2);
         }
         t[i] = (uint16_t)v;
     }
@@ -489,13 +496,16 @@ __device__ inline uint32_t crc16_piece(const uint4 v, const uint16_t *piece)
     return c;
 }
 
-// CRC-16 of every candidate span [goff[r], next), next = the following candidate of the
-// same stream or the end of the stream.  One wave per span at a time (waves stride over
-// the spans); lanes load consecutive 16-byte vectors (1 KiB per wave per step), reduce
-// each to its remainder with table lookups, and carry it over the 1 KiB stride by a
-// table multiplication; the 64 partial remainders are weighted by lane and XOR-ed.
-__global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__ in, const StreamDev *__restrict__ streams,
-                                                     CandArrays c, uint32_t n_cand, const uint16_t *__restrict__ tables)
+// CRC-16 of every candidate span [goff[r], goff[r] + seglen[r]).  One wave per span at a time (waves
+// stride over the spans).  The span is cut into 16-byte pieces on 16-byte boundaries; the bytes of the
+// first piece before the span and of the last piece after it are taken as zeros (leading zeros do not
+// change a CRC that starts from zero; trailing zeros multiply it by a known power of x, divided out at
+// the end).  Lanes load consecutive pieces (1 KiB per wave per step), reduce each to its remainder with
+// sixteen table lookups, and carry it over the 1 KiB stride by a table multiplication; at the end the 64
+// partial remainders are weighted by lane and XOR-ed.  The next step's piece (or the first piece of the
+// wave's next span) is loaded before the current one is processed.
+__global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__ in, CandArrays c, uint32_t n_cand,
+                                                     const uint16_t *__restrict__ tables)
 {
     __shared__ __align__(16) uint16_t s_t[kCrcTableEntries];
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries / 2; i += blockDim.x)
@@ -505,50 +515,66 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t lanew = s_t[kCrcLane + lane];
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_cand; r += waves) {
-        const uint64_t a = c.goff[r];
-        const uint32_t si = c.stream[r];
-        uint64_t b = streams[si].in_off + streams[si].in_len;
-        if (r + 1 < n_cand && c.stream[r + 1] == si) b = c.goff[r + 1];
-        const uint64_t A = a & ~(uint64_t)15;
-        const uint32_t lead = (uint32_t)(a - A);
-        const uint32_t nfull = (uint32_t)((b - A) >> 4), rem = (uint32_t)((b - A) & 15);
-        const uint32_t steps = (nfull + 63) >> 6, pad = steps * 64 - nfull;
-        const uint4 *src = reinterpret_cast<const uint4 *>(in + A);
-        uint32_t acc = 0;
-        for (uint32_t t = 0; t < steps; ++t) {
-            const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)pad;
-            uint32_t pc = 0;
-            if (j >= 0) {
-                uint4 v = src[j];
-                if (j == 0 && lead) {   // bytes before the span count as zeros (no effect with init 0)
-                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+
+    struct Span { uint64_t A; uint32_t lead, npieces, steps, pad, trail; };
+    auto geometry = [&](uint64_t a, uint32_t len) {
+        Span g;
+        g.A = a & ~(uint64_t)15;
+        g.lead = (uint32_t)(a - g.A);
+        const uint32_t total = g.lead + len;
+        g.npieces = (total + 15) >> 4;
+        g.trail = (16 - (total & 15)) & 15;          // zero bytes after the span in its last piece
+        g.steps = (g.npieces + 63) >> 6;
+        g.pad = g.steps * 64 - g.npieces;            // empty lanes in front of the first step
+        return g;
+    };
+    auto load_piece = [&](const Span &g, uint32_t t) {
+        const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)g.pad;
+        return (j >= 0 && g.npieces) ? *reinterpret_cast<const uint4 *>(in + g.A + (uint64_t)j * 16) : uint4{0u, 0u, 0u, 0u};
+    };
+    // keeps bytes [from, to) of a piece
+    auto keep_bytes = [](uint4 v, uint32_t from, uint32_t to) {
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int32_t nz = (int32_t)lead - 4 * i;
-                        if (nz >= 4) w[i] = 0;
-                        else if (nz > 0) w[i] &= 0xFFFFFFFFu << (8 * nz);
-                    }
-                    v = uint4{w[0], w[1], w[2], w[3]};
-                }
-                pc = crc16_piece(v, piece);
+        for (int i = 0; i < 4; ++i) {
+            const int32_t lo = (int32_t)from - 4 * i, hi = (int32_t)to - 4 * i;   // kept byte range inside word i
+            uint32_t m = 0xFFFFFFFFu;
+            if (lo >= 4 || hi <= 0) m = 0;
+            else {
+                if (lo > 0) m &= 0xFFFFFFFFu << (8 * lo);
+                if (hi < 4) m &= 0xFFFFFFFFu >> (8 * (4 - hi));
             }
+            w[i] &= m;
+        }
+        return uint4{w[0], w[1], w[2], w[3]};
+    };
+
+    uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n_cand) return;
+    Span g = geometry(c.goff[r], c.seglen[r]);
+    uint4 cur = load_piece(g, 0);
+    while (r < n_cand) {
+        const uint32_t r_next = r + waves;
+        Span g_next = g;
+        if (r_next < n_cand) g_next = geometry(c.goff[r_next], c.seglen[r_next]);
+        uint32_t acc = 0;
+        for (uint32_t t = 0; t < g.steps; ++t) {
+            uint4 nxt = uint4{0u, 0u, 0u, 0u};
+            if (t + 1 < g.steps) nxt = load_piece(g, t + 1);
+            else if (r_next < n_cand) nxt = load_piece(g_next, 0);
+            const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)g.pad;
+            if (t == 0 && g.lead && j == 0) cur = keep_bytes(cur, g.lead, 16);
+            if (t + 1 == g.steps && g.trail && j == (int32_t)g.npieces - 1) cur = keep_bytes(cur, 0, 16 - g.trail);
+            const uint32_t pc = crc16_piece(cur, piece);
             acc = skip[acc & 0xFF] ^ skip[256 + (acc >> 8)] ^ pc;
+            cur = nxt;
         }
         acc = gf_mulmod(acc, lanew);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) acc ^= __shfl_xor(acc, d);
-        if (lane == 0) {
-            const uint32_t crc = gf_mulmod(acc, s_t[kCrcRem + rem]);
-            // the bytes after the last whole vector (at most 15), byte at a time:
-            // crc = (crc << 8) ^ T[(crc >> 8) ^ byte] with T[v] = v * x^16 = piece[0][v]
-            uint32_t tcrc = 0;
-            const uint64_t t0 = A + ((uint64_t)nfull << 4);
-            for (uint64_t g = (t0 > a ? t0 : a); g < b; ++g)
-                tcrc = ((tcrc << 8) & 0xFFFF) ^ piece[(tcrc >> 8) ^ in[g]];
-            c.segcrc[r] = (uint16_t)(crc ^ tcrc);
-            c.seglen[r] = (uint32_t)(b - a);
-        }
+        if (lane == 0) c.segcrc[r] = (uint16_t)(g.trail ? gf_mulmod(acc, s_t[kCrcInv + g.trail]) : acc);
+        r = r_next;
+        g = g_next;
     }
 }
 
