@@ -571,19 +571,18 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // whole-dword write-out needs every frame's destination 4-byte aligned
     const bool dwords = (CB & 3) == 0 && !__any(active && ((reinterpret_cast<uint64_t>(p.out) + dst) & 3));
     __builtin_amdgcn_wave_barrier();
-    // 16-bit stereo write-out: this lane packs sample column (lane & 15) of frames 4*it + (lane >> 4);
-    // their channel assignments, 4 bits each
-    // and where they go (offset of this lane's column from p.out) and how long they are
+    // 16-bit stereo write-out: this lane packs sample columns 4*(lane & 3) .. +3 of frames 16*it + (lane >> 2),
+    // it = 0, 1.  Their channel assignments (4 bits each), where they go (offset of the lane's first
+    // column from p.out) and how long they are:
     uint32_t modes = 0;
-    uint64_t fdst[STEREO16 ? 8 : 1];
-    uint32_t fbs[STEREO16 ? 8 : 1];
-    fdst[0] = 0; fbs[0] = 0;
+    uint64_t fdst[2] = {0, 0};
+    uint32_t fbs[2] = {0, 0};
     if (STEREO16) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t f = it * 4 + (lane >> 4);
+        for (int it = 0; it < 2; ++it) {
+            const uint32_t f = it * 16 + (lane >> 2);
             modes |= (s_mode[f] & 15u) << (4 * it);
-            fdst[it] = s_dst[f] + (lane & 15) * 4;
+            fdst[it] = s_dst[f] + (lane & 3) * 16;
             fbs[it] = s_bs[f];
         }
     }
@@ -717,23 +716,39 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     auto flush = [&](uint32_t t0) {
         __builtin_amdgcn_wave_barrier();
         if (STEREO16) {
-            // one output word (left | right << 16) per lane and step: 16 lanes write 64 contiguous bytes of one frame
-            const uint32_t col = lane & 15;
-            uint2 ab[8];
+            // four output words (left | right << 16) per lane and step: 4 lanes write 64 contiguous bytes of one frame
+            const uint32_t c4 = (lane & 3) * 4;
+            uint2 ab[2][4];
 #pragma unroll
-            for (int it = 0; it < 8; ++it)
-                ab[it] = *reinterpret_cast<const uint2 *>(tile_raw + col * kRawStride + 2 * (it * 4 + (lane >> 4)));
+            for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const uint32_t a = ab[it].x, b = ab[it].y, m = (modes >> (4 * it)) & 15u;
-                // mid/side: left = mid + ceil(side / 2), right = mid - floor(side / 2)
-                const uint32_t L = m == 10 ? a + (uint32_t)(((int32_t)b + 1) >> 1) : m == 9 ? a + b : a;
-                const uint32_t R = m == 10 ? a - (uint32_t)((int32_t)b >> 1) : m == 8 ? a - b : b;
-                const uint32_t word = (L & 0xFFFFu) | (R << 16);
-                if (t0 + col < fbs[it]) {
-                    uint8_t *at = p.out + fdst[it] + (uint64_t)t0 * 4;
-                    if (dwords) *reinterpret_cast<uint32_t *>(at) = word;
-                    else { at[0] = (uint8_t)word; at[1] = (uint8_t)(word >> 8); at[2] = (uint8_t)(word >> 16); at[3] = (uint8_t)(word >> 24); }
+                for (int i = 0; i < 4; ++i)
+                    ab[it][i] = *reinterpret_cast<const uint2 *>(tile_raw + (c4 + i) * kRawStride + 2 * (it * 16 + (lane >> 2)));
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const uint32_t m = (modes >> (4 * it)) & 15u;
+                uint32_t word[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t a = ab[it][i].x, b = ab[it][i].y;
+                    // mid/side: left = mid + ceil(side / 2), right = mid - floor(side / 2)
+                    const uint32_t L = m == 10 ? a + (uint32_t)(((int32_t)b + 1) >> 1) : m == 9 ? a + b : a;
+                    const uint32_t R = m == 10 ? a - (uint32_t)((int32_t)b >> 1) : m == 8 ? a - b : b;
+                    word[i] = (L & 0xFFFFu) | (R << 16);
+                }
+                const uint32_t n = t0 + c4;
+                uint8_t *at = p.out + fdst[it] + (uint64_t)t0 * 4;
+                if (dwords && n + 4 <= fbs[it]) {
+                    *reinterpret_cast<uint4 *>(at) = uint4{word[0], word[1], word[2], word[3]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (n + i < fbs[it]) {
+                            uint8_t *q = at + 4 * i;
+                            const uint32_t x = word[i];
+                            if (dwords) *reinterpret_cast<uint32_t *>(q) = x;
+                            else { q[0] = (uint8_t)x; q[1] = (uint8_t)(x >> 8); q[2] = (uint8_t)(x >> 16); q[3] = (uint8_t)(x >> 24); }
+                        }
                 }
             }
         } else {
