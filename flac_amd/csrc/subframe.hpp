@@ -41,6 +41,10 @@ constexpr uint32_t kUnitWords = 8;    // refill granule: 32 bytes
 constexpr uint32_t kRoundSteps = 8;   // decode steps (of at most 32 bits) between refill rounds
 constexpr uint32_t kRingBytesPerWave = kRingSlots * 64 * 4;
 constexpr uint32_t kNoFill = 0xFFFFFFFFu;
+#ifndef FLACGPU_SKIM_PAIR_K
+#define FLACGPU_SKIM_PAIR_K 9
+#endif
+constexpr uint32_t kSkimPairK = FLACGPU_SKIM_PAIR_K;
 
 // MSB-first reader over one lane's bitstream.  Its whole state is a bit position P, counted from the
 // 64-byte-aligned address at or before the frame's first byte.  Stream word w of the lane sits at
@@ -399,7 +403,10 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
                 const uint32_t s_P = br.P;
                 uint32_t longest = 0;
                 bool starved = false;
-                const bool pairs = __all(!reads || k <= 12);
+                // Two codes per window only pay when a pair seldom exceeds 32 bits: one lane that has to be redone
+                // costs the whole wave a walk through the group.  With Rice parameter k the unary parts of a pair
+                // may total 30 - 2k.  The limit on k is tuned on synthetic audio (7: 26 % slower than 9; 9, 11, 14 equal).
+                const bool pairs = __all(!reads || k <= kSkimPairK);
                 if (pairs) {
                     // two codes per window: the second is read from the window shifted by the first
 #pragma unroll
