@@ -205,6 +205,18 @@ def main():
         alg_bytes = comp_total + pcm_total            # per launch of the decode kernel (one rank)
         dec_s = kernel_ms["decode_ms"] / 1e3
         achieved = alg_bytes / dec_s / 1e9 if dec_s > 0 else 0.0
+        # HBM traffic of the dominant kernel: counters cannot be read from inside this process, so the figure
+        # comes from the committed rocprofv3 --pmc passes over this same command (profiles/), scaled by files
+        traffic, traffic_note = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_c_pmc_traffic.json")))
+            kd = pmc["kernels"]["k_decode<12, 0, true>"]
+            traffic = (2.0 * kd["FETCH_SIZE_KiB"] + kd["WRITE_SIZE_KiB"]) * 1024.0 * nfiles / pmc["files"]
+            traffic_note = (f"(2 x FETCH_SIZE + WRITE_SIZE) of k_decode from profiles/r1_c_pmc_traffic.json, measured at "
+                            f"{pmc['files']} files and scaled to {nfiles}; the factor 2 is calibrated for coalesced reads "
+                            f"only and is an upper bound for this kernel's 32-byte sector reads")
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "decoded PCM samples/sec",
             "value": values_all * args.steps / elapsed,
@@ -228,7 +240,7 @@ def main():
             "algorithmic_GB_per_s": (pcm_all + comp_all) * args.steps / elapsed / 1e9,
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms["decode_ms"]},
             "cpu_baseline": cpu,
         }

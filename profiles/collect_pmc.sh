@@ -1,16 +1,20 @@
 #!/bin/bash
 # Counter passes over the bench (run on the GPU box from the repository root).  One pass per rocprofv3
-# run; each run holds at most 8 SQ or 4 TCC counters.  Output: gpurun_out/pmc_<tag>/.
+# run; each run holds at most 8 SQ or 4 TCC counters.  Output: gpurun_out/pmc_<tag>/ and .txt summaries.
 set -e
 export TMPDIR=/tmp
 ARGS="bench.py --files ${PMC_FILES:-2000} --steps 2 --warmup 1 --cpu-files 0"
 pass() {
     tag=$1; shift
-    timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -o p -- python3 $ARGS > gpurun_out/pmc_$tag.log 2>&1
-    python3 profiles/pmc_summary.py gpurun_out/pmc_$tag/*counter_collection.csv > gpurun_out/pmc_$tag.txt
+    timeout -s KILL 400 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -o p -- python3 $ARGS > gpurun_out/pmc_$tag.log 2>&1
+    python3 profiles/pmc_summary.py gpurun_out/pmc_$tag/*counter_collection.csv > gpurun_out/pmc_$tag.txt; echo "pass $tag done"
 }
-pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
-pass sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM
-pass fetch FETCH_SIZE
-pass write WRITE_SIZE
-pass grbm GRBM_GUI_ACTIVE
+for p in ${PMC_PASSES:-sq1 sq2 fetch write grbm}; do
+    case $p in
+        sq1) pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY ;;
+        sq2) pass sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM ;;
+        fetch) pass fetch FETCH_SIZE ;;
+        write) pass write WRITE_SIZE ;;
+        grbm) pass grbm GRBM_GUI_ACTIVE ;;
+    esac
+done
