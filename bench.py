@@ -42,6 +42,15 @@ def main():
     ap.add_argument("--files", type=int, default=10000)
     ap.add_argument("--unique", type=int, default=256)
     ap.add_argument("--seconds", type=float, default=60.0)
+    # the defaults are the headline workload; the options below exist to time other stream shapes
+    ap.add_argument("--rate", type=int, default=44100)
+    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--bps", type=int, default=16)
+    ap.add_argument("--blocksize", type=int, default=4096)
+    ap.add_argument("--lpc-order", type=int, default=12, help="maximum LPC order")
+    ap.add_argument("--force-lpc-order", type=int, default=0)
+    ap.add_argument("--partition-order", type=int, default=6, help="maximum Rice partition order")
+    ap.add_argument("--force-partition-order", type=int, default=-1)
     ap.add_argument("--cpu-files", type=int, default=256, help="files of the workload timed on the host CPU (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU sample is decoded repeatedly for about this long")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
@@ -61,16 +70,22 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    rate, channels, bps, blocksize = 44100, 2, 16, 4096
+    rate, channels, bps, blocksize = args.rate, args.channels, args.bps, args.blocksize
     nsamples = int(round(args.seconds * rate))
-    pcm_bytes_per_file = nsamples * channels * 2
+    bytes_ps = (bps + 7) // 8
+    pcm_bytes_per_file = nsamples * channels * bytes_ps
     unique = max(1, min(args.unique, args.files))
 
     # ---- corpus: UNIQUE files synthesised + encoded on the host ------------------------------
     threads = args.cpu_threads or min(16, os.cpu_count() or 1)
     enc_threads = max(1, threads // max(1, min(world, 8))) if world > 1 else threads
     t0 = time.time()
-    opts = synth.options(blocksize, 12, max_partition_order=6)
+    okw = dict(max_partition_order=args.partition_order)
+    if args.force_lpc_order:
+        okw["force_lpc_order"] = args.force_lpc_order
+    if args.force_partition_order >= 0:
+        okw["force_partition_order"] = args.force_partition_order
+    opts = synth.options(blocksize, args.lpc_order, **okw)
     files, ffs = synth.make_batch(rank * unique, unique, nsamples, channels, bps, rate, opts, nthreads=enc_threads)
     infos, audios = [], []
     for f, ff in zip(files, ffs):
@@ -228,11 +243,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": "int32" if bps <= 16 else "int64",
             "data": "synthetic",
             "config": {
-                "workload": f"{nfiles} x {args.seconds:g} s 44.1 kHz 16-bit stereo FLAC, blocksize 4096, fixed+LPC(<=12), "
-                            f"{unique} unique files replicated in HBM",
+                "workload": f"{nfiles} x {args.seconds:g} s {rate / 1000:g} kHz {bps}-bit {channels}-channel FLAC, blocksize {blocksize}, "
+                            f"fixed+LPC(<={args.lpc_order})" + (f" forced order {args.force_lpc_order}" if args.force_lpc_order else "")
+                            + (f", Rice partition order {args.force_partition_order}" if args.force_partition_order >= 0 else "")
+                            + f", {unique} unique files replicated in HBM",
                 "files_per_gpu": nfiles, "unique_files": unique,
                 "compressed_GB_per_gpu": comp_total / 1e9, "pcm_GB_per_gpu": pcm_total / 1e9,
             },

@@ -393,7 +393,7 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
         HIP_TRY(hipMemsetAsync(p.class_flags, 0, 6 * sizeof(uint32_t), st));
         // every predictor-length class is launched over the same grid; a wave runs in exactly one
 #define FLACGPU_LAUNCH(MO, W, S) \
-        k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C, r.B, S), st>>>(p); p.check_flag = 1
+        k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C), st>>>(p); p.check_flag = 1
         if (r.C == 2 && r.B == 2) {
             FLACGPU_LAUNCH(12, 0, true); FLACGPU_LAUNCH(32, 0, true); FLACGPU_LAUNCH(12, 1, true);
             FLACGPU_LAUNCH(32, 1, true); FLACGPU_LAUNCH(12, 2, true); FLACGPU_LAUNCH(32, 2, true);

@@ -476,27 +476,24 @@ struct DecodeParams {
 // order among its lanes.  U = history ring size and unroll factor, NT = taps.
 __host__ __device__ constexpr int class_unroll(int nt) { return nt <= 16 ? 16 : 32; }
 
-constexpr uint32_t kTile = 32;    // samples staged in LDS between write-outs (packed tile)
-constexpr uint32_t kTile16 = 16;  // samples staged per write-out in the 16-bit stereo kernels (raw tile)
-constexpr uint32_t kRawStride = 66;   // words per sample column of the raw tile: 64 lanes + 2, so that the
-                                      // write-out's 8-byte reads (16 lanes, one frame, 16 columns) cover all banks once
+constexpr uint32_t kTile = 16;        // samples staged in LDS between write-outs
+constexpr uint32_t kRawStride = 66;   // words per sample column of the tile: 64 lanes + 2, so that the write-out's
+                                      // 8-byte reads of 16-bit stereo (16 lanes: 4 frames x 4 columns) cover all banks once
 
-// LDS bytes one wave needs: the refill ring, the sample tile and per-frame destination, block size, mode.
-// Packed tile (general kernels): rows of kTile samples x C channels x B bytes per frame, padded by 4 bytes so
-// that rows start on different banks.  Raw tile (16-bit stereo): one 32-bit word per lane and sample.
-__host__ __device__ inline uint32_t decode_wave_lds(uint32_t C, uint32_t B, bool stereo16)
+// LDS bytes one wave needs: the refill ring, the sample tile (one 32-bit word per lane and sample: samples are
+// staged as coded, whatever the output format) and per-frame destination, block size and channel assignment.
+__host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 {
-    const uint32_t F = 64 / C, row_stride = kTile * C * B + 4;
-    const uint32_t tile = stereo16 ? kTile16 * kRawStride * 4 : ((F * row_stride + 15) & ~15u);
-    return kRingBytesPerWave + tile + F * 16;
+    return kRingBytesPerWave + kTile * kRawStride * 4 + (64 / C) * 16;
 }
 
 // One lane per (frame, channel); a wave holds floor(64 / C) frames.
 // NT: predictor taps evaluated per sample (12 or 32).
 // ARITH: 0 = 24-bit multiplies (every subframe of the wave is at most 24 bits wide),
 //        1 = 32-bit multiplies, 2 = 64-bit sums.
-// STEREO16: C == 2 and B == 2.  Lanes stage their samples as coded; decorrelation and packing to
-//           one 32-bit word per sample pair happen in the write-out, once per output word.
+// STEREO16: C == 2 and B == 2, the write-out specialised for it.
+// Lanes stage their samples as coded; stereo decorrelation and packing to the output's sample size happen
+// in the write-out, once per output word.
 //
 // Samples are processed in groups of U.  A group in which every lane is in the
 // middle of a Rice partition (or constant / finished) runs the unrolled fast
@@ -509,7 +506,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int U = class_unroll(NT);
-    constexpr uint32_t kT = STEREO16 ? kTile16 : kTile;
+    constexpr uint32_t kT = kTile;
     // The instantiation launched first runs every wave and flags the classes its waves turn out to belong
     // to; the launches that follow are over in microseconds when no wave is theirs.
     if (p.check_flag && p.class_flags[(NT == 12 ? 0 : 1) + 2 * ARITH] == 0) return;
@@ -517,9 +514,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     const uint32_t CB = C * B;
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
     const uint32_t F = 64 / C;
-    const uint32_t row_stride = kTile * CB + 4;
-    const uint32_t wave_bytes = decode_wave_lds(C, B, STEREO16);
-    const uint32_t tile_bytes = STEREO16 ? kTile16 * kRawStride * 4 : ((F * row_stride + 15) & ~15u);
+    const uint32_t wave_bytes = decode_wave_lds(C);
+    const uint32_t tile_bytes = kTile * kRawStride * 4;
     uint32_t *wave_ring = reinterpret_cast<uint32_t *>(smem + wave_in_block * wave_bytes);
     uint8_t *tile = smem + wave_in_block * wave_bytes + kRingBytesPerWave;
     uint32_t *tile_raw = reinterpret_cast<uint32_t *>(tile);
@@ -575,8 +571,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 
     const uint32_t bs_max = wave_max_u32(active ? bs : 0);
     if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; s_mode[fl] = ca; }
-    // whole-dword write-out needs every frame's destination 4-byte aligned
-    const bool dwords = (CB & 3) == 0 && !__any(active && ((reinterpret_cast<uint64_t>(p.out) + dst) & 3));
+    // whole-dword write-out needs every frame's destination 4-byte aligned (a tile row of kTile samples is a
+    // whole number of dwords for every sample size and channel count)
+    const bool dwords = !__any(active && ((reinterpret_cast<uint64_t>(p.out) + dst) & 3));
     __builtin_amdgcn_wave_barrier();
     // 16-bit stereo write-out: this lane packs sample columns 4*(lane & 3) .. +3 of frames 16*it + (lane >> 2),
     // it = 0, 1.  Their channel assignments (4 bits each), where they go (offset of the lane's first
@@ -584,6 +581,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     uint32_t modes = 0;
     uint64_t fdst[2] = {0, 0};
     uint32_t fbs[2] = {0, 0};
+    // Other layouts: a frame's 16 samples x C channels are 16C sample slots in output order; a work item is
+    // four consecutive slots of one frame (= B output dwords), 4C items per frame, item = 64 * it + lane,
+    // it = 0 .. 3.  Divisions by C and 4C are multiplications by rounded-up 16-bit reciprocals (exact while
+    // dividend x divisor < 2^16; dividends here are below 256, divisors at most 32).
+    const uint32_t inv_c = 65536u / C + 1, inv_4c = 65536u / (4 * C) + 1;
     if (STEREO16) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -656,33 +658,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // when v is in range, and the OR of those sums is tested once at the end.
     const uint32_t sbits = h.sbps ? h.sbps : 32u;
     const uint32_t half = 1u << (sbits - 1);
-    const bool is_ls = ca == 8, is_sr = ca == 9, is_ms = ca == 10;
     uint32_t ovf = 0;
     auto emit = [&](int32_t v, bool live, uint32_t col, auto always) {
-        constexpr bool ALWAYS = decltype(always)::value;   // fast groups store from every lane: a dead lane's row is never written out
+        constexpr bool ALWAYS = decltype(always)::value;   // fast groups store from every lane: a dead lane's column is never written out
         ovf |= (uint32_t)v + half;
-        uint32_t o = (uint32_t)v << h.wasted;
-        if (STEREO16) {
-            if (ALWAYS || live) tile_raw[col * kRawStride + lane] = o;
-        } else {
-            if (C == 2) {
-                // exchange with the other lane of the pair (quad_perm [1,0,3,2])
-                const uint32_t q = (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
-                const uint32_t a = ch == 0 ? o : q, b = ch == 0 ? q : o;   // channel 0 / channel 1 as coded
-                const uint32_t mm = (a << 1) | (b & 1);
-                const uint32_t mL = (uint32_t)((int32_t)(mm + b) >> 1), mR = (uint32_t)((int32_t)(mm - b) >> 1);
-                const uint32_t L = is_ms ? mL : is_sr ? a + b : a;
-                const uint32_t R = is_ms ? mR : is_ls ? a - b : b;
-                o = ch == 0 ? L : R;
-            }
-            if ((ALWAYS && fl < F) || live) {   // lanes past the last whole frame of the wave own no tile row
-                uint8_t *t = tile + fl * row_stride + (col * C + ch) * B;
-                if (B == 2) *reinterpret_cast<uint16_t *>(t) = (uint16_t)o;
-                else if (B == 4) *reinterpret_cast<uint32_t *>(t) = o;
-                else if (B == 3) { t[0] = (uint8_t)o; t[1] = (uint8_t)(o >> 8); t[2] = (uint8_t)(o >> 16); }
-                else t[0] = (uint8_t)o;
-            }
-        }
+        if (ALWAYS || live) tile_raw[col * kRawStride + lane] = (uint32_t)v << h.wasted;
     };
     // Sum of coef[j] * x[j] over the NT taps in the wave's arithmetic class, shifted.  The taps are
     // summed in three independent chains and the most recent sample (tap 0) is added last: a dependent
@@ -719,6 +699,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             return sum >> shift;
         }
     };
+    // Undoes the inter-channel decorrelation of one sample pair (channel assignment m: 8 left/side,
+    // 9 side/right, 10 mid/side; mid/side: left = mid + ceil(side / 2), right = mid - floor(side / 2)).
+    auto decorrelate = [](uint32_t m, uint32_t a, uint32_t b, uint32_t &L, uint32_t &R) {
+        L = m == 10 ? a + (uint32_t)(((int32_t)b + 1) >> 1) : m == 9 ? a + b : a;
+        R = m == 10 ? a - (uint32_t)((int32_t)b >> 1) : m == 8 ? a - b : b;
+    };
     // Write-out of the staged samples [t0, t0 + kT) of every frame of this wave.
     auto flush = [&](uint32_t t0) {
         __builtin_amdgcn_wave_barrier();
@@ -738,14 +724,13 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint32_t a = ab[it][i].x, b = ab[it][i].y;
-                    // mid/side: left = mid + ceil(side / 2), right = mid - floor(side / 2)
-                    const uint32_t L = m == 10 ? a + (uint32_t)(((int32_t)b + 1) >> 1) : m == 9 ? a + b : a;
-                    const uint32_t R = m == 10 ? a - (uint32_t)((int32_t)b >> 1) : m == 8 ? a - b : b;
+                    uint32_t L, R;
+                    decorrelate(m, a, b, L, R);
                     word[i] = (L & 0xFFFFu) | (R << 16);
                 }
                 const uint32_t n = t0 + c4;
                 uint8_t *at = p.out + fdst[it] + (uint64_t)t0 * 4;
-                if (dwords && n + 4 <= fbs[it]) {
+                if (dwords && n + 4 <= fbs[it] && (reinterpret_cast<uint64_t>(at) & 15) == 0) {
                     *reinterpret_cast<uint4 *>(at) = uint4{word[0], word[1], word[2], word[3]};
                 } else {
 #pragma unroll
@@ -759,23 +744,48 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 }
             }
         } else {
-            const uint32_t row_bytes = kTile * CB;
-            if (dwords) {
-                const uint32_t row_words = row_bytes >> 2;
-                for (uint32_t i = lane; i < F * row_words; i += 64) {
-                    const uint32_t f = i / row_words, col = i - f * row_words;
-                    const uint32_t fbs = s_bs[f];
-                    const uint32_t valid = fbs > t0 ? min(kTile, fbs - t0) * CB : 0;
-                    if (col * 4 < valid)
-                        *reinterpret_cast<uint32_t *>(p.out + s_dst[f] + (uint64_t)t0 * CB + col * 4) =
-                            *reinterpret_cast<const uint32_t *>(tile + f * row_stride + col * 4);
+#pragma unroll 1
+            for (uint32_t it = 0; it < 4; ++it) {
+                const uint32_t item = it * 64 + lane, f = (item * inv_4c) >> 16, g = item - f * 4 * C;
+                if (f >= F) continue;
+                const uint32_t fbs_f = s_bs[f];
+                if (t0 >= fbs_f) continue;
+                const uint32_t ncols = min(kTile, fbs_f - t0);   // sample columns of this tile that exist in the frame
+                uint32_t v[4], nvalid = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t slot = 4 * g + j, col = (slot * inv_c) >> 16, chn = slot - col * C;
+                    v[j] = tile_raw[col * kRawStride + f * C + chn];
+                    nvalid += col < ncols ? 1u : 0u;
                 }
-            } else {
-                for (uint32_t i = lane; i < F * row_bytes; i += 64) {
-                    const uint32_t f = i / row_bytes, col = i - f * row_bytes;
-                    const uint32_t fbs = s_bs[f];
-                    const uint32_t valid = fbs > t0 ? min(kTile, fbs - t0) * CB : 0;
-                    if (col < valid) p.out[s_dst[f] + (uint64_t)t0 * CB + col] = tile[f * row_stride + col];
+                if (C == 2) {   // slots are (a, b) of two consecutive samples
+                    const uint32_t m = s_mode[f] & 15u;
+                    uint32_t L, R;
+                    decorrelate(m, v[0], v[1], L, R); v[0] = L; v[1] = R;
+                    decorrelate(m, v[2], v[3], L, R); v[2] = L; v[3] = R;
+                }
+                // the 4 * B output bytes as dwords d0 .. d(B-1)
+                uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];   // B == 4
+                if (B == 1) d0 = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
+                if (B == 2) { d0 = (v[0] & 0xFFFFu) | (v[1] << 16); d1 = (v[2] & 0xFFFFu) | (v[3] << 16); }
+                if (B == 3) {
+                    d0 = (v[0] & 0xFFFFFFu) | (v[1] << 24);
+                    d1 = ((v[1] >> 8) & 0xFFFFu) | (v[2] << 16);
+                    d2 = ((v[2] >> 16) & 0xFFu) | (v[3] << 8);
+                }
+                uint8_t *at = p.out + s_dst[f] + (uint64_t)t0 * CB + g * 4 * B;
+                if (dwords && nvalid == 4) {
+                    uint32_t *q = reinterpret_cast<uint32_t *>(at);   // 4-byte aligned; wider stores would need more
+                    q[0] = d0;
+                    if (B >= 2) q[1] = d1;
+                    if (B >= 3) q[2] = d2;
+                    if (B >= 4) q[3] = d3;
+                } else {
+                    // a block that ends inside these four slots, or an odd destination: byte by byte
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((uint32_t)j < nvalid)
+                            for (uint32_t y = 0; y < B; ++y) at[j * B + y] = (uint8_t)(v[j] >> (8 * y));
                 }
             }
         }
@@ -792,7 +802,6 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     const bool trailing = __any(active && status == kFrameOK && kind == 2 && order >= bs);
     const uint32_t n_end = ((bs_max + U - 1) / U) * U + (trailing ? U : 0);
     for (uint32_t n0 = 0; n0 < n_end; n0 += U) {
-        const uint32_t col0 = n0 & (kT - 1);   // the group's first column in its tile
         ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
         const bool on = active && status == kFrameOK && n0 < bs;
         if (on && kind == 2 && started && part_rem == 0) next_partition();
@@ -839,8 +848,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 const int32_t pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
                 const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
                 ring[P] = v;
-                emit(v, on, STEREO16 ? ((uint32_t)P & (kT - 1)) : col0 + (uint32_t)P, std::true_type{});
-                if (STEREO16 && U > (int)kTile16 && P == (int)kTile16 - 1) flush(n0);
+                emit(v, on, (uint32_t)P & (kT - 1), std::true_type{});
+                if (U > (int)kTile && P == (int)kTile - 1) flush(n0);
             }
             starved = starved || br.starved();
 #ifdef FLACGPU_DEBUG_FORCE_REDO
@@ -850,12 +859,6 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             // as 2^32 - 1 zeros), so the test never misses one; it is wrong the safe way now and then.
             redo = rice_on && (starved || longest_q > 31 - k);
 #endif
-            if (C == 2 && !STEREO16) {
-                // the two lanes of a stereo pair exchange samples: they are redone together
-                // (the exchange must run in every lane, so it is not the right-hand side of a short-circuit ||)
-                const int partner = __builtin_amdgcn_mov_dpp((int)redo, 0xB1, 0xF, 0xF, true);
-                redo = redo | (partner != 0);
-            }
             if (rice_on && !redo) part_rem -= U;
             run_generic = __any(redo);
             if (redo || !rice_on) br.P = s_P;
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             for (uint32_t n = n0; n < n0 + U; ++n) {
                 if (n != n0 && ((n - n0) % kRoundSteps) == 0)
                     ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
-                if (STEREO16 && U > (int)kTile16 && n - n0 == kTile16) flush(n0);
+                if (U > (int)kTile && n - n0 == kTile) flush(n0);
                 const bool ok = active && status == kFrameOK && redo;
                 const bool live = ok && n < bs;
                 if (ok && kind == 2 && !started && n >= order) {

@@ -31,6 +31,11 @@ CASES = [
     dict(name="lpc32-16bit", channels=2, bps=16, n=9000, bs=4096, max_lpc_order=32),
     dict(name="mono24-odd", channels=1, bps=24, n=5001, bs=1001),
     dict(name="tiny", channels=2, bps=16, n=17, bs=4096),
+    dict(name="stereo16-odd-bs", channels=2, bps=16, n=5005, bs=1001),
+    dict(name="stereo24-bs1002", channels=2, bps=24, n=5010, bs=1002),
+    dict(name="6ch16", channels=6, bps=16, n=7000, bs=1152, rate=48000),
+    dict(name="stereo8", channels=2, bps=8, n=5000, bs=512),
+    dict(name="mono32", channels=1, bps=32, n=3000, bs=512),
 ]
 
 
