@@ -1,0 +1,263 @@
+// flac.hpp — C++ host layer over the C ABI of libflacgpu, shaped like the reference Go package `flac`
+// (flacmeta.go): the same type and field names, the same block numbering, Read() leaving the stream on
+// byte 0 of audio frame 0, errors as returned strings where Go returns `error` (empty = nil).
+//
+// Only the blocks the frame engine needs (STREAMINFO, SEEKTABLE, PADDING) and VORBIS_COMMENT are carried
+// with their payload; APPLICATION, CUESHEET and PICTURE blocks are walked over (their headers are kept in
+// Blocks), as the frame path has no use for them.
+//
+// The frame engine itself (Decoder) has no counterpart in the reference, which stops at the first frame
+// (flacmeta.go:845-849); it takes what Read left behind.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <istream>
+#include <string>
+#include <vector>
+
+#include "../../include/flacgpu.h"
+
+namespace flac {
+
+// MetadataBlockType, flacmeta.go:25-37: FlacSignature takes value 0, so STREAMINFO = 1 ... PICTURE = 7.
+enum MetadataBlockType : uint32_t {
+    FlacSignature = 0,
+    MetadataStreaminfo = 1,
+    MetadataPadding = 2,
+    MetadataApplication = 3,
+    MetadataSeektable = 4,
+    MetadataVorbisComment = 5,
+    MetadataCuesheet = 6,
+    MetadataPicture = 7,
+    MetadataInvalid = 127,
+};
+
+// (MetadataBlockType).String, flacmeta.go:174-194
+inline const char *String(MetadataBlockType t)
+{
+    switch (t) {
+    case MetadataStreaminfo: return "STREAMINFO";
+    case MetadataPadding: return "PADDING";
+    case MetadataApplication: return "APPLICATION";
+    case MetadataSeektable: return "SEEKTABLE";
+    case MetadataVorbisComment: return "VORBIS_COMMENT";
+    case MetadataCuesheet: return "CUESHEET";
+    case MetadataPicture: return "PICTURE";
+    default: return "INVALID";
+    }
+}
+
+struct MetadataBlockHeader {   // flacmeta.go:235-240
+    MetadataBlockType Type = MetadataInvalid;
+    uint32_t Length = 0;
+    bool Last = false;
+    bool operator==(const MetadataBlockHeader &o) const { return Type == o.Type && Length == o.Length && Last == o.Last; }
+};
+
+struct SeekpointBlock {        // flacmeta.go:256-260
+    uint64_t SampleNumber = 0;
+    uint64_t Offset = 0;
+    uint16_t FrameSamples = 0;
+    bool operator==(const SeekpointBlock &o) const
+    {
+        return SampleNumber == o.SampleNumber && Offset == o.Offset && FrameSamples == o.FrameSamples;
+    }
+};
+
+struct StreaminfoBlock {       // flacmeta.go:263-273
+    uint16_t MinBlockSize = 0, MaxBlockSize = 0;
+    uint32_t MinFrameSize = 0, MaxFrameSize = 0;
+    uint32_t SampleRate = 0;
+    uint8_t Channels = 0, BitsPerSample = 0;
+    uint64_t TotalSamples = 0;
+    std::string MD5Signature;  // 32 hex digits, as the reference stores it (flacmeta.go:707-715)
+    bool operator==(const StreaminfoBlock &o) const
+    {
+        return MinBlockSize == o.MinBlockSize && MaxBlockSize == o.MaxBlockSize && MinFrameSize == o.MinFrameSize &&
+               MaxFrameSize == o.MaxFrameSize && SampleRate == o.SampleRate && Channels == o.Channels &&
+               BitsPerSample == o.BitsPerSample && TotalSamples == o.TotalSamples && MD5Signature == o.MD5Signature;
+    }
+};
+
+struct VorbisCommentBlock {    // flacmeta.go:276-280
+    std::string Vendor;
+    uint32_t TotalComments = 0;
+    std::vector<std::string> Comments;
+    bool operator==(const VorbisCommentBlock &o) const
+    {
+        return Vendor == o.Vendor && TotalComments == o.TotalComments && Comments == o.Comments;
+    }
+};
+
+// Complete blocks (header + data), flacmeta.go:288-334.
+struct Padding { MetadataBlockHeader Header; bool IsPopulated = false; };
+struct Streaminfo { MetadataBlockHeader Header; StreaminfoBlock Data; bool IsPopulated = false; };
+struct VorbisComment { MetadataBlockHeader Header; VorbisCommentBlock Data; bool IsPopulated = false; };
+struct Seektable {
+    MetadataBlockHeader Header;
+    std::vector<SeekpointBlock> Data;
+    bool IsPopulated = false;
+    int TotalPoints() const { return (int)Data.size(); }   // flacmeta.go:607-609
+};
+
+inline std::string hex(const uint8_t *b, size_t n)
+{
+    static const char *d = "0123456789abcdef";
+    std::string s;
+    for (size_t i = 0; i < n; ++i) { s += d[b[i] >> 4]; s += d[b[i] & 15]; }
+    return s;
+}
+
+// Metadata, flacmeta.go:337-346.
+struct Metadata {
+    flac::Streaminfo Streaminfo;
+    flac::VorbisComment VorbisComment;
+    flac::Padding Padding;
+    flac::Seektable Seektable;
+    std::vector<MetadataBlockHeader> Blocks;   // every block in file order, payloads not kept
+    uint8_t TotalBlocks = 0;
+    uint64_t FirstFrameOffset = 0;             // where Read leaves the stream
+
+    // (*Metadata).Read, flacmeta.go:749-850.  Returns "" on success, otherwise the error text.  On success
+    // `f` is positioned on the first byte of the first audio frame.
+    std::string Read(std::istream &f)
+    {
+        // the metadata area is read block by block, like the reference does: 4 bytes of signature,
+        // then a 4-byte header and its payload per block
+        std::vector<uint8_t> buf(4);
+        if (!f.read(reinterpret_cast<char *>(buf.data()), 4)) return "error reading FLAC signature: unexpected EOF";
+        if (std::string(buf.begin(), buf.end()) != "fLaC") return "\"" + std::string(buf.begin(), buf.end()) + "\" is not a valid FLAC signature";
+        for (;;) {
+            const size_t at = buf.size();
+            buf.resize(at + 4);
+            if (!f.read(reinterpret_cast<char *>(buf.data() + at), 4)) return "error reading metadata block header: unexpected EOF";
+            flacgpu_block hb;
+            if (int rc = flacgpu_parse_block_header(buf.data() + at, 4, &hb))
+                return std::string("failed to marshalMetadataBlockHeader: ") + flacgpu_status_string(rc);
+            buf.resize(at + 4 + hb.length);
+            if (hb.length && !f.read(reinterpret_cast<char *>(buf.data() + at + 4), hb.length)) {
+                char msg[160];
+                std::snprintf(msg, sizeof msg, "failed to read %lld of %u bytes for %s metadata block: unexpected EOF",
+                              (long long)f.gcount(), hb.length, String((MetadataBlockType)hb.type));
+                return msg;
+            }
+            if (hb.last) break;
+        }
+        flacgpu_metadata md;
+        if (int rc = flacgpu_parse_metadata(buf.data(), buf.size(), &md)) {
+            if (rc == FLACGPU_ERR_DUPLICATE) return "two blocks of a kind that may appear once encountered";
+            if (rc == FLACGPU_ERR_SEEKTABLE) return "SEEKTABLE block length is not a multiple of 18";
+            return std::string("metadata: ") + flacgpu_status_string(rc);
+        }
+        FirstFrameOffset = md.first_frame_offset;
+        TotalBlocks = (uint8_t)md.n_blocks;
+        for (uint32_t i = 0; i < md.n_blocks; ++i) {
+            const flacgpu_block &b = md.blocks[i];
+            MetadataBlockHeader h;
+            h.Type = (MetadataBlockType)b.type; h.Length = b.length; h.Last = b.last != 0;
+            Blocks.push_back(h);
+            const uint8_t *p = buf.data() + b.payload_offset;
+            switch (h.Type) {
+            case MetadataStreaminfo: {
+                Streaminfo.Header = h; Streaminfo.IsPopulated = true;
+                const flacgpu_streaminfo &s = md.streaminfo;
+                Streaminfo.Data.MinBlockSize = s.min_blocksize; Streaminfo.Data.MaxBlockSize = s.max_blocksize;
+                Streaminfo.Data.MinFrameSize = s.min_framesize; Streaminfo.Data.MaxFrameSize = s.max_framesize;
+                Streaminfo.Data.SampleRate = s.sample_rate; Streaminfo.Data.Channels = s.channels;
+                Streaminfo.Data.BitsPerSample = s.bits_per_sample; Streaminfo.Data.TotalSamples = s.total_samples;
+                Streaminfo.Data.MD5Signature = hex(s.md5, 16);
+                break;
+            }
+            case MetadataPadding: Padding.Header = h; Padding.IsPopulated = true; break;
+            case MetadataSeektable: {
+                Seektable.Header = h; Seektable.IsPopulated = true;
+                std::vector<flacgpu_seekpoint> pts(b.length / 18 + 1);
+                size_t n = 0;
+                if (int rc = flacgpu_parse_seektable(p, b.length, pts.data(), pts.size(), &n))
+                    return std::string("SEEKTABLE: ") + flacgpu_status_string(rc);
+                for (size_t k = 0; k < n; ++k) {
+                    SeekpointBlock sp;
+                    sp.SampleNumber = pts[k].sample_number; sp.Offset = pts[k].offset; sp.FrameSamples = pts[k].frame_samples;
+                    Seektable.Data.push_back(sp);
+                }
+                break;
+            }
+            case MetadataVorbisComment: {
+                // MarshalVorbisCommentBlock, flacmeta.go:720-746: little-endian lengths, vendor, then the comments
+                VorbisComment.Header = h; VorbisComment.IsPopulated = true;
+                auto le32 = [&](size_t o) { return (uint32_t)p[o] | (uint32_t)p[o + 1] << 8 | (uint32_t)p[o + 2] << 16 | (uint32_t)p[o + 3] << 24; };
+                size_t o = 0;
+                if (b.length < 8) return "VORBIS_COMMENT block too short";
+                const uint32_t vl = le32(o); o += 4;
+                if (o + vl + 4 > b.length) return "VORBIS_COMMENT block too short";
+                VorbisComment.Data.Vendor.assign(reinterpret_cast<const char *>(p + o), vl); o += vl;
+                VorbisComment.Data.TotalComments = le32(o); o += 4;
+                for (uint32_t k = 0; k < VorbisComment.Data.TotalComments; ++k) {
+                    if (o + 4 > b.length) return "VORBIS_COMMENT block too short";
+                    const uint32_t cl = le32(o); o += 4;
+                    if (o + cl > b.length) return "VORBIS_COMMENT block too short";
+                    VorbisComment.Data.Comments.emplace_back(reinterpret_cast<const char *>(p + o), cl); o += cl;
+                }
+                break;
+            }
+            default: break;
+            }
+        }
+        return "";
+    }
+};
+
+// Result of decoding one stream (flacgpu_stream_result).
+struct StreamResult {
+    uint64_t HeaderCandidates = 0, Frames = 0, FramesOK = 0, Samples = 0, PCMBytes = 0;
+};
+
+// One GPU's frame engine (flacgpu_create / flacgpu_destroy).
+class Decoder {
+public:
+    Decoder() = default;
+    Decoder(const Decoder &) = delete;
+    Decoder &operator=(const Decoder &) = delete;
+    ~Decoder() { Close(); }
+    // NewDecoder: returns "" or the error text
+    std::string Open(int device)
+    {
+        flacgpu_options o;
+        o.struct_size = sizeof o; o.device = device; o.flags = 0; o.reserved = 0;
+        if (int rc = flacgpu_create(&o, &h_)) return std::string("flacgpu_create: ") + flacgpu_status_string(rc);
+        return "";
+    }
+    void Close() { if (h_) flacgpu_destroy(h_); h_ = nullptr; }
+
+    // Decodes the frames that follow the metadata: `f` as Read left it.  pcm receives the interleaved
+    // little-endian samples the STREAMINFO MD5 is defined over.
+    std::string DecodeFrames(const Metadata &m, std::istream &f, std::vector<uint8_t> &pcm, StreamResult &res)
+    {
+        if (!h_) return "decoder is not open";
+        if (!m.Streaminfo.IsPopulated) return "DecodeFrames needs the STREAMINFO that Read produced";
+        std::vector<uint8_t> audio((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const StreaminfoBlock &s = m.Streaminfo.Data;
+        flacgpu_streaminfo si;
+        si.min_blocksize = s.MinBlockSize; si.max_blocksize = s.MaxBlockSize;
+        si.min_framesize = s.MinFrameSize; si.max_framesize = s.MaxFrameSize;
+        si.sample_rate = s.SampleRate; si.channels = s.Channels; si.bits_per_sample = s.BitsPerSample;
+        si.total_samples = s.TotalSamples;
+        for (int i = 0; i < 16; ++i) si.md5[i] = (uint8_t)std::stoi(s.MD5Signature.substr(2 * i, 2), nullptr, 16);
+        pcm.assign((size_t)(s.TotalSamples * s.Channels * ((s.BitsPerSample + 7) / 8)), 0);
+        const uint8_t *in = audio.data();
+        const uint64_t len = audio.size(), cap = pcm.size();
+        uint8_t *out = pcm.data();
+        flacgpu_stream_result r;
+        if (int rc = flacgpu_decode_batch(h_, &in, &len, &si, 1, &out, &cap, &r))
+            return std::string("decode: ") + flacgpu_status_string(rc) + ": " + flacgpu_last_error(h_);
+        res.HeaderCandidates = r.header_candidates; res.Frames = r.frames; res.FramesOK = r.frames_ok;
+        res.Samples = r.samples; res.PCMBytes = r.pcm_bytes;
+        return "";
+    }
+
+private:
+    flacgpu_handle *h_ = nullptr;
+};
+
+}  // namespace flac
