@@ -19,6 +19,8 @@ OK = 0
 FRAME_OK, FRAME_BAD_CRC16, FRAME_BAD_SUBFRAME, FRAME_TRUNCATED, FRAME_LENGTH, FRAME_RANGE, FRAME_UNSUPPORTED, \
     FRAME_SKIPPED = range(8)
 FLAG_TIMING = 1
+ENC_MD5 = 1
+ERR_CAPACITY = 8
 MAX_BLOCKS = 128
 
 # MetadataBlockType values as the reference numbers them (flacmeta.go:28-37).
@@ -102,11 +104,46 @@ class Timing(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class EncodeOptions(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("blocksize", ctypes.c_uint32), ("max_lpc_order", ctypes.c_uint32),
+                ("qlp_precision", ctypes.c_uint32), ("min_partition_order", ctypes.c_uint32),
+                ("max_partition_order", ctypes.c_uint32), ("stereo_mode", ctypes.c_int32),
+                ("force_lpc_order", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+def encode_options(blocksize=4096, max_lpc_order=12, qlp_precision=0, min_partition_order=0, max_partition_order=6,
+                   stereo_mode=-1, force_lpc_order=0, flags=0) -> EncodeOptions:
+    return EncodeOptions(ctypes.sizeof(EncodeOptions), blocksize, max_lpc_order, qlp_precision, min_partition_order,
+                         max_partition_order, stereo_mode, force_lpc_order, flags, 0)
+
+
+class PcmStream(ctypes.Structure):
+    _fields_ = [("in_offset", ctypes.c_uint64), ("total_samples", ctypes.c_uint64), ("out_offset", ctypes.c_uint64),
+                ("out_capacity", ctypes.c_uint64), ("sample_rate", ctypes.c_uint32), ("channels", ctypes.c_uint8),
+                ("bits_per_sample", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 2), ("md5", ctypes.c_uint8 * 16)]
+
+
+class EncodeResult(ctypes.Structure):
+    _fields_ = [("out_length", ctypes.c_uint64), ("frames", ctypes.c_uint64), ("min_framesize", ctypes.c_uint32),
+                ("max_framesize", ctypes.c_uint32), ("status", ctypes.c_int32), ("reserved", ctypes.c_uint32),
+                ("md5", ctypes.c_uint8 * 16)]
+
+
+class EncodeTiming(ctypes.Structure):
+    _fields_ = [("analyze_ms", ctypes.c_float), ("layout_ms", ctypes.c_float), ("pack_ms", ctypes.c_float),
+                ("crc_ms", ctypes.c_float), ("md5_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("frames", ctypes.c_uint64), ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 # Every symbol include/flacgpu.h declares.
 EXPORTS = [
     "flacgpu_parse_block_header", "flacgpu_parse_streaminfo", "flacgpu_parse_seektable", "flacgpu_parse_metadata",
     "flacgpu_status_string", "flacgpu_create", "flacgpu_destroy", "flacgpu_last_error", "flacgpu_scan_frames",
     "flacgpu_decode_batch_device", "flacgpu_decode_batch", "flacgpu_get_timing",
+    "flacgpu_encode_bound", "flacgpu_encode_batch_device", "flacgpu_encode_batch", "flacgpu_get_encode_timing",
 ]
 
 _lib = None
@@ -154,6 +191,14 @@ def lib():
                                            u32, ctypes.POINTER(vp), ctypes.POINTER(u64),
                                            ctypes.POINTER(StreamResult)]
         L.flacgpu_get_timing.argtypes = [vp, ctypes.POINTER(Timing)]
+        L.flacgpu_encode_bound.restype = u64
+        L.flacgpu_encode_bound.argtypes = [u64, u32, u32, u32]
+        L.flacgpu_encode_batch_device.argtypes = [vp, vp, u64, vp, u64, ctypes.POINTER(PcmStream), u32,
+                                                  ctypes.POINTER(EncodeOptions), ctypes.POINTER(EncodeResult), vp]
+        L.flacgpu_encode_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(PcmStream), u32,
+                                           ctypes.POINTER(EncodeOptions), ctypes.POINTER(vp), ctypes.POINTER(u64),
+                                           ctypes.POINTER(EncodeResult)]
+        L.flacgpu_get_encode_timing.argtypes = [vp, ctypes.POINTER(EncodeTiming)]
         _lib = L
     return _lib
 
@@ -286,6 +331,58 @@ class Decoder:
         t = Timing()
         self._check(lib().flacgpu_get_timing(self._h, ctypes.byref(t)))
         return t
+
+    # ---- encoder
+
+    @staticmethod
+    def make_pcm_streams(entries):
+        """entries: iterable of (in_offset, total_samples, out_offset, out_capacity, sample_rate, channels, bps[, md5])."""
+        entries = list(entries)
+        arr = (PcmStream * len(entries))()
+        for i, e in enumerate(entries):
+            (arr[i].in_offset, arr[i].total_samples, arr[i].out_offset, arr[i].out_capacity, arr[i].sample_rate,
+             arr[i].channels, arr[i].bits_per_sample) = e[:7]
+            if len(e) > 7 and e[7] is not None:
+                arr[i].md5[:] = list(e[7])
+        return arr
+
+    def encode_batch_device(self, d_pcm, pcm_bytes, d_out, out_bytes, streams, opts: EncodeOptions, hip_stream=0):
+        n = len(streams)
+        res = (EncodeResult * n)()
+        rc = lib().flacgpu_encode_batch_device(self._h, _ptr(d_pcm), pcm_bytes, _ptr(d_out), out_bytes, streams, n,
+                                               ctypes.byref(opts), res, hip_stream or None)
+        self._check(rc)
+        return res
+
+    def encode_batch(self, pcm_list, shapes, opts: EncodeOptions):
+        """Host buffers in, host .flac streams out.  pcm_list: packed little-endian PCM per stream;
+        shapes: per stream (total_samples, sample_rate, channels, bps[, md5])."""
+        n = len(pcm_list)
+        arrs = [np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8)) for a in pcm_list]
+        caps = [encode_bound(sh[0], sh[2], sh[3], opts.blocksize) for sh in shapes]
+        outs = [np.zeros(c, dtype=np.uint8) for c in caps]
+        streams = self.make_pcm_streams((0, sh[0], 0, 0, sh[1], sh[2], sh[3], sh[4] if len(sh) > 4 else None)
+                                        for sh in shapes)
+        iptr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        optr = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ocap = (ctypes.c_uint64 * n)(*caps)
+        res = (EncodeResult * n)()
+        rc = lib().flacgpu_encode_batch(self._h, iptr, streams, n, ctypes.byref(opts), optr, ocap, res)
+        self._check(rc)
+        return [o[: int(r.out_length)] for o, r in zip(outs, res)], list(res)
+
+    def encode_timing(self) -> EncodeTiming:
+        t = EncodeTiming()
+        self._check(lib().flacgpu_get_encode_timing(self._h, ctypes.byref(t)))
+        return t
+
+
+Engine = Decoder
+
+
+def encode_bound(total_samples, channels, bps, blocksize) -> int:
+    """flacgpu_encode_bound: a capacity that always fits one encoded stream."""
+    return int(lib().flacgpu_encode_bound(int(total_samples), int(channels), int(bps), int(blocksize)))
 
 
 def decode_file(path_or_bytes, decoder: Decoder = None):

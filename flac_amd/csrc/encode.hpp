@@ -1,0 +1,1062 @@
+// encode.hpp — gfx950 kernels of the batched FLAC encoder (RFC 9639 frames behind a
+// STREAMINFO block laid out as flacmeta.go:644-717 reads it).
+//
+// One encode call runs:
+//   k_enc_analyze  workgroup per (frame, candidate channel): wasted bits, constant test, fixed-predictor
+//                  error sums, windowed autocorrelation, Levinson-Durbin, coefficient quantisation,
+//                  residuals, Rice partition search -> a "plan" with the exact subframe size in bits
+//   k_enc_layout   workgroup per stream: stereo decision per frame, frame sizes, their prefix sum (= where
+//                  every frame and subframe goes), frame headers, STREAMINFO
+//   k_enc_pack     workgroup per (frame, channel): residuals again, code lengths, their prefix sum, bits
+//                  assembled in LDS and copied to the frame's place
+//   (CRC-16 of every frame by the decoder's span kernel), k_enc_write_crc
+//   k_enc_md5      lane per stream, optional
+//
+// A block of bs samples is cut into runs of kRun = 16 consecutive samples, one per lane.  All
+// floating-point sums are formed in a fixed order (per lane ascending, butterfly over the wave,
+// waves ascending) so that a scalar restatement of the same order gives the same bits.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flacgpu {
+
+constexpr int kRun = 16;
+constexpr int kEncMaxBs = 16384;
+constexpr int kEncMaxPo = 8;
+constexpr int kPlanHeadBytes = 16;
+constexpr int kPlanCoefBytes = 64;   // 32 x int16
+
+struct EncStreamDev {
+    uint64_t in_off;          // bytes from d_pcm to sample 0
+    uint64_t out_off;         // bytes from d_out to the "fLaC" marker
+    uint64_t out_cap;
+    uint64_t total_samples;   // inter-channel
+    uint64_t out_len;         // result: bytes written
+    uint32_t frame_begin;     // index of frame 0 in the frame arrays
+    uint32_t n_frames;
+    uint32_t unit_begin;      // index of (frame 0, candidate 0) in the plan array
+    uint32_t pack_begin;      // index of (frame 0, channel 0) among the pack units
+    uint32_t sample_rate;
+    uint32_t tail_bs;         // samples in the last frame
+    uint32_t win_off;         // floats from the window table to the window of a full block
+    uint32_t win_off_tail;    // ... of the last block
+    uint32_t min_fs, max_fs;  // result
+    int32_t  status;          // result
+    uint8_t  channels, bps, bytes_ps, ncand;
+    uint8_t  md5[16];
+    uint32_t pad[3];
+};
+
+struct EncOptsDev {
+    uint32_t blocksize, max_lpc_order, qlp_precision, min_po, max_po;
+    int32_t  stereo_mode;
+    uint32_t force_lpc_order;
+    uint32_t plan_stride;     // bytes per plan
+    uint32_t total_units, total_pack, total_frames;
+};
+
+struct PlanHead {             // kPlanHeadBytes
+    uint32_t bits;            // exact size of the subframe
+    uint8_t  type;            // 0 constant, 1 verbatim, 2 fixed, 3 lpc
+    uint8_t  order, wasted, sb, prec, shift, po, method;
+    uint32_t pad;
+};
+
+struct FrameRec {             // 64 bytes
+    uint64_t out_off;         // byte offset of the frame in d_out
+    uint32_t bytes;           // 0: not written (its stream does not fit its capacity)
+    uint32_t stream;
+    uint32_t bs;
+    uint8_t  hdr_len, ch_assign;
+    uint8_t  cand[8];         // candidate plan used by each channel
+    uint8_t  pad[2];
+    uint32_t sf_bit[8];       // bit offset of each subframe from the frame start
+};
+
+// ------------------------------------------------------------------ helpers ---
+
+__device__ inline uint32_t wave_or(uint32_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v |= (uint32_t)__shfl_xor((int)v, m);
+    return v;
+}
+__device__ inline uint32_t wave_sum32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m);
+    return v;
+}
+__device__ inline uint32_t wave_min32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, m); v = o < v ? o : v; }
+    return v;
+}
+__device__ inline uint32_t wave_max32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, m); v = o > v ? o : v; }
+    return v;
+}
+__device__ inline uint64_t wave_sum64(uint64_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += (uint64_t)__shfl_xor((long long)v, m);
+    return v;
+}
+// Butterfly sum: every lane ends with the same value, formed in the same order.
+__device__ inline double wave_butterfly(double v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m);
+    return v;
+}
+
+// Exclusive prefix sum over the workgroup; s_w needs NT / 64 entries.
+template <int NT>
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = (uint32_t)__shfl_up((int)inc, d);
+        if (lane >= (uint32_t)d) inc += n;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const uint32_t x = s_w[w];
+        if ((uint32_t)w < wave) base += x;
+        tot += x;
+    }
+    total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__device__ inline int ilog2_32(uint32_t v) { return 31 - __clz((int)v); }
+__device__ inline int ilog2_64(uint64_t v) { return 63 - __clzll((long long)v); }
+__device__ inline uint32_t fold(int32_t r) { return ((uint32_t)r << 1) ^ (uint32_t)(r >> 31); }
+
+// Signed little-endian sample of B bytes.
+__device__ inline int32_t load_le(const uint8_t *p, int B)
+{
+    uint32_t v;
+    if (B == 2) v = *reinterpret_cast<const uint16_t *>(p);
+    else {
+        v = p[0];
+        if (B > 2) v |= ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    }
+    const int sh = 32 - 8 * B;
+    return (int32_t)(v << sh) >> sh;
+}
+
+// Sample i of candidate channel `cand` of a frame whose interleaved PCM starts at src.
+// Stereo streams have four candidates: left, right, mid = (l + r) >> 1, side = l - r.
+__device__ inline int32_t cand_sample(const uint8_t *src, uint32_t i, int C, int B, int cand, bool stereo4)
+{
+    if (stereo4) {
+        int32_t l, r;
+        if (B == 2) {
+            const uint32_t lr = *reinterpret_cast<const uint32_t *>(src + (size_t)i * 4);
+            l = (int32_t)(lr << 16) >> 16;
+            r = (int32_t)lr >> 16;
+        } else {
+            l = load_le(src + (size_t)(2 * i) * B, B);
+            r = load_le(src + (size_t)(2 * i + 1) * B, B);
+        }
+        return cand == 0 ? l : cand == 1 ? r : cand == 2 ? (l + r) >> 1 : l - r;
+    }
+    return load_le(src + ((size_t)i * C + cand) * B, B);
+}
+
+__device__ inline int find_enc_stream(const EncStreamDev *s, uint32_t n, uint32_t idx, int which)
+{
+    uint32_t lo = 0, hi = n;   // last stream whose begin <= idx
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t b = which == 0 ? s[mid].unit_begin : s[mid].pack_begin;
+        if (b <= idx) lo = mid; else hi = mid;
+    }
+    return (int)lo;
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin; this makes consecutive units share an XCD (and its L2).
+__device__ inline uint32_t xcd_unit(uint32_t bid, uint32_t grid)
+{
+    const uint32_t per = grid >> 3;
+    return (bid & 7) * per + (bid >> 3);
+}
+
+// log2 of a positive normal number: exponent plus a cubic fit on [1, 2), plain multiplications and additions.
+__device__ inline double est_log2(double v)
+{
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    const int e = (int)((b >> 52) & 0x7FF) - 1023;
+    b = (b & 0xFFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    const double m = __longlong_as_double((long long)b);
+    const double x = m - 1.0;
+    double p = 0x1.48f04fbb3fa68p-4 * x;
+    p = p + -0x1.e4bf84b19febep-3;
+    p = p * x;
+    p = p + 0x1.c09645d8fab54p-2;
+    double y = x * (1.0 - x);
+    y = y * p;
+    return ((double)e + x) + y;
+}
+
+__device__ inline int default_precision(int bps, uint32_t bs)
+{
+    if (bps < 16) { const int p = 2 + bps / 2; return p < 5 ? 5 : p; }
+    if (bps == 16)
+        return bs <= 192 ? 7 : bs <= 384 ? 8 : bs <= 576 ? 9 : bs <= 1152 ? 10 : bs <= 2304 ? 11 : bs <= 4608 ? 12 : 13;
+    return bs <= 384 ? 13 : bs <= 1152 ? 14 : 15;
+}
+
+// Rice parameter of one partition from the sum of its folded residuals: the cheapest of four parameters
+// around log2(sum / count) by the estimate count * (k + 1) + (sum >> k).
+__device__ inline uint32_t rice_param(uint64_t sum, uint32_t cnt, uint32_t &est)
+{
+    if (cnt == 0) { est = 0; return 0; }
+    if (sum == 0) { est = cnt; return 0; }
+    const int k0 = ilog2_64(sum) - ilog2_32(cnt);
+    int lo = k0 - 2, hi = k0 + 1;
+    lo = lo < 0 ? 0 : lo > 30 ? 30 : lo;
+    hi = hi < 0 ? 0 : hi > 30 ? 30 : hi;
+    uint64_t best = ~0ull;
+    int bk = lo;
+    for (int k = lo; k <= hi; ++k) {
+        const uint64_t b = (uint64_t)cnt * (uint64_t)(k + 1) + (sum >> k);
+        if (b < best) { best = b; bk = k; }
+    }
+    est = (uint32_t)best;
+    return (uint32_t)bk;
+}
+
+// Largest usable partition order: whole runs per partition and room for the warm-up in partition 0.
+__device__ inline int max_partition_order(uint32_t bs, uint32_t order, uint32_t max_po)
+{
+    int L = (int)(max_po > (uint32_t)kEncMaxPo ? (uint32_t)kEncMaxPo : max_po);
+    while (L > 0 && ((bs % ((uint32_t)kRun << L)) != 0 || (bs >> L) < order + 1)) --L;
+    return L;
+}
+
+// Residual of a fixed predictor, 32-bit wrapping arithmetic.  w[M + j] is the lane's sample j.
+template <int M>
+__device__ inline void fixed_residual(const int32_t (&w)[M + kRun], int order, uint32_t (&u)[kRun])
+{
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const uint32_t a = (uint32_t)w[M + j], b = (uint32_t)w[M + j - 1], c = (uint32_t)w[M + j - 2],
+                       d = (uint32_t)w[M + j - 3], e = (uint32_t)w[M + j - 4];
+        uint32_t r;
+        switch (order) {
+        case 0: r = a; break;
+        case 1: r = a - b; break;
+        case 2: r = a - 2 * b + c; break;
+        case 3: r = a - 3 * b + 3 * c - d; break;
+        default: r = a - 4 * b + 6 * c - 4 * d + e; break;
+        }
+        u[j] = fold((int32_t)r);
+    }
+}
+
+// LPC residual.  MODE 0: 24-bit multiplies (samples of at most 24 bits, coefficients of at most 15),
+// 1: 32-bit wrapping sums, 2: 64-bit sums.  Bit j of the result is set when residual j does not fit 32 bits.
+template <int M, int MODE>
+__device__ inline uint32_t lpc_residual(const int32_t (&w)[M + kRun], const int32_t (&cq)[M], int shift, uint32_t (&u)[kRun])
+{
+    uint32_t bad = 0;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        int64_t pred;
+        if (MODE == 2) {
+            int64_t s = 0;
+#pragma unroll
+            for (int q = 0; q < M; ++q) s += (int64_t)cq[q] * (int64_t)w[M + j - 1 - q];
+            pred = s >> shift;
+        } else {
+            uint32_t s = 0;
+#pragma unroll
+            for (int q = 0; q < M; ++q)
+                s += MODE == 0 ? (uint32_t)__mul24(cq[q], w[M + j - 1 - q]) : (uint32_t)cq[q] * (uint32_t)w[M + j - 1 - q];
+            pred = (int32_t)s >> shift;
+        }
+        const int64_t r = (int64_t)w[M + j] - pred;
+        bad |= (uint32_t)((r != (int64_t)(int32_t)r) || (r == -2147483647LL - 1)) << j;
+        u[j] = fold((int32_t)r);
+    }
+    return bad;
+}
+
+// ----------------------------------------------------------------- analysis ---
+
+template <int NT>
+struct AnalyzeShared {
+    uint64_t psum[2][NT];            // per lane: sum of folded residuals (0 fixed, 1 lpc)
+    uint64_t heap[2][512];           // partition sums, node n has children 2n and 2n + 1
+    uint64_t e[5];                   // fixed-predictor error sums
+    double   wsum[NT / 64][17];      // per wave autocorrelation sums of one lag group
+    double   ac[33];
+    double   tmp[32], best[32];
+    uint32_t lvl_total[2][kEncMaxPo + 1];
+    uint32_t need5[2];
+    uint32_t exact[2];
+    uint32_t ored, neq, lpc_bad;
+    int32_t  q[32];
+    int32_t  fo, lpc_ok, ord, prec, shift, wide;
+    int32_t  po[2], method[2], L[2], lo[2];
+    uint8_t  kb[2][512];
+};
+
+// Levinson-Durbin, order choice and coefficient quantisation, run by one thread.
+template <int NT>
+__device__ __noinline__ void design_predictor(AnalyzeShared<NT> &S, const EncOptsDev &o, uint32_t bs, int sb, int stream_bps,
+                                              uint32_t maxo)
+{
+    S.lpc_ok = 0; S.ord = 0;
+    if (!(S.ac[0] > 0)) return;
+    int prec0 = o.qlp_precision ? (int)o.qlp_precision : default_precision(stream_bps, bs);
+    prec0 = prec0 > 15 ? 15 : prec0 < 5 ? 5 : prec0;
+    double err = S.ac[0], bestb = 0;
+    const double scale = 0x1.0a6a4c7c29f9ap+0 / (double)bs;   // 0.5 / ln(2)^2 / bs
+    int ord = 0;
+    for (uint32_t i = 0; i < maxo; ++i) {
+        double r = -S.ac[i + 1];
+        for (uint32_t j = 0; j < i; ++j) r -= S.tmp[j] * S.ac[i - j];
+        if (err <= 0) break;
+        r /= err;
+        S.tmp[i] = r;
+        for (uint32_t j = 0; j < i / 2; ++j) {
+            const double t = S.tmp[j];
+            S.tmp[j] += r * S.tmp[i - 1 - j];
+            S.tmp[i - 1 - j] += r * t;
+        }
+        if (i & 1) S.tmp[i / 2] += S.tmp[i / 2] * r;
+        err *= (1.0 - r * r);
+        const uint32_t k = i + 1;
+        bool take;
+        if (o.force_lpc_order) take = (k == o.force_lpc_order);
+        else {
+            const double v = err * scale;
+            double bpr = v > 0 ? 0.5 * est_log2(v) : 0.0;
+            if (bpr < 0) bpr = 0;
+            const double tot = bpr * (double)(bs - k) + (double)k * (double)(sb + prec0);
+            take = (ord == 0 || tot < bestb);
+            if (take) bestb = tot;
+        }
+        if (take) { ord = (int)k; for (uint32_t j = 0; j < k; ++j) S.best[j] = -S.tmp[j]; }
+    }
+    if (!ord) return;
+    int prec = prec0;
+    if (sb <= 17 && !o.qlp_precision) {
+        const int cap = 32 - sb - ilog2_32((uint32_t)ord);
+        if (prec > cap) prec = cap;
+    }
+    double cmax = 0;
+    for (int j = 0; j < ord; ++j) { const double a = __builtin_fabs(S.best[j]); if (a > cmax) cmax = a; }
+    if (!(cmax > 0)) return;
+    const uint64_t cb = (uint64_t)__double_as_longlong(cmax);
+    const int ex = (int)((cb >> 52) & 0x7FF) - 1022;
+    int shift = prec - ex - 1;
+    if (shift > 15) shift = 15;
+    const int qmax = (1 << (prec - 1)) - 1, qmin = -qmax - 1;
+    const double mul = shift >= 0 ? (double)(1 << shift) : 1.0 / (double)(1 << -shift);
+    if (shift < 0) shift = 0;
+    double carry = 0;
+    for (int j = 0; j < 32; ++j) S.q[j] = 0;
+    for (int j = 0; j < ord; ++j) {
+        carry += S.best[j] * mul;
+        int v = carry >= 0 ? (int)(carry + 0.5) : -(int)(0.5 - carry);
+        v = v > qmax ? qmax : v < qmin ? qmin : v;
+        carry -= (double)v;
+        S.q[j] = v;
+    }
+    S.ord = ord; S.prec = prec; S.shift = shift;
+    S.wide = (sb + prec + ilog2_32((uint32_t)ord)) > 32;
+    S.lpc_ok = 1;
+}
+
+// Partition search of one predictor's residual: fills S.po / S.method / S.kb / S.exact for slot `which`.
+// Called by the whole workgroup.  u: the lane's folded residuals, order: warm-up samples.
+template <int NT>
+__device__ inline void rice_search(AnalyzeShared<NT> &S, const EncOptsDev &o, int which, uint32_t bs, uint32_t order,
+                                   const uint32_t (&u)[kRun])
+{
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint32_t lanes = (bs + kRun - 1) / kRun;
+    const int L = max_partition_order(bs, order, o.max_po);
+    const int lo = (int)o.min_po > L ? L : (int)o.min_po;
+    const uint32_t P = 1u << L, tpp = L ? (bs >> L) / kRun : lanes;
+    uint64_t *heap = S.heap[which];
+    if (L == 0) {
+        const uint64_t ws = wave_sum64(t < lanes ? S.psum[which][t] : 0);
+        if (lane == 0 && ws) atomicAdd((unsigned long long *)&heap[1], (unsigned long long)ws);
+    } else if (t < P) {
+        uint64_t s = 0;
+        for (uint32_t q = 0; q < tpp; ++q) s += S.psum[which][t * tpp + q];
+        heap[P + t] = s;
+    }
+    __syncthreads();
+    for (int l = L - 1; l >= lo; --l) {
+        if (t < (1u << l)) { const uint32_t n = (1u << l) + t; heap[n] = heap[2 * n] + heap[2 * n + 1]; }
+        __syncthreads();
+    }
+    for (uint32_t n = (1u << lo) + t; n < (2u << L); n += NT) {
+        const int l = ilog2_32(n);
+        const uint32_t p = n - (1u << l);
+        const uint32_t cnt = (bs >> l) - (p == 0 ? order : 0);
+        uint32_t est;
+        const uint32_t k = rice_param(heap[n], cnt, est);
+        S.kb[which][n] = (uint8_t)k;
+        atomicAdd(&S.lvl_total[which][l], est);
+        if (k > 14) atomicOr(&S.need5[which], 1u << l);
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t best = 0xFFFFFFFFu;
+        int bl = L, bm = 0;
+        for (int l = L; l >= lo; --l) {
+            const int n5 = (S.need5[which] >> l) & 1;
+            const uint32_t total = S.lvl_total[which][l] + ((n5 ? 5u : 4u) << l);
+            if (total < best) { best = total; bl = l; bm = n5; }
+        }
+        S.po[which] = bl; S.method[which] = bm;
+    }
+    __syncthreads();
+    const int po = S.po[which];
+    const uint32_t part = po ? (t * kRun) / (bs >> po) : 0;
+    uint32_t exact = 0;
+    if (t < lanes) {
+        const uint32_t k = S.kb[which][(1u << po) + (part < (1u << po) ? part : 0)];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t * kRun + j;
+            if (i >= order && i < bs) exact += (u[j] >> k) + k + 1;
+        }
+    }
+    exact = wave_sum32(exact);
+    if (lane == 0 && exact) atomicAdd(&S.exact[which], exact);
+}
+
+template <int M, int NT>
+__global__ __launch_bounds__(NT) void k_enc_analyze(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
+                                                    uint32_t n_streams, EncOptsDev o, const float *__restrict__ windows,
+                                                    uint8_t *__restrict__ plans)
+{
+    extern __shared__ __align__(16) int32_t xs[];   // M zeros, then NT * kRun samples
+    __shared__ AnalyzeShared<NT> S;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x);
+    if (unit >= o.total_units) return;
+    const int si = find_enc_stream(streams, n_streams, unit, 0);
+    const EncStreamDev &st = streams[si];
+    const uint32_t ncand = st.ncand, rel = unit - st.unit_begin;
+    const uint32_t f = rel / ncand, cand = rel - f * ncand;
+    const bool last = f + 1 == st.n_frames;
+    const uint32_t bs = last ? st.tail_bs : o.blocksize;
+    const float *win = windows + (last ? st.win_off_tail : st.win_off);
+    const int C = st.channels, B = st.bytes_ps, stream_bps = st.bps;
+    const bool stereo4 = ncand == 4;
+    const int cbps = stream_bps + (stereo4 && cand == 3 ? 1 : 0);
+    const uint8_t *src = pcm + st.in_off + (uint64_t)f * o.blocksize * (uint32_t)(C * B);
+    uint8_t *plan = plans + (uint64_t)unit * o.plan_stride;
+    const uint32_t lanes = (bs + kRun - 1) / kRun;
+
+    if (t == 0) {
+        S.ored = 0; S.neq = 0; S.lpc_bad = 0; S.lpc_ok = 0; S.ord = 0;
+        for (int k = 0; k < 5; ++k) S.e[k] = 0;
+        for (int w = 0; w < 2; ++w) {
+            S.need5[w] = 0; S.exact[w] = 0; S.heap[w][1] = 0;
+            for (int l = 0; l <= kEncMaxPo; ++l) S.lvl_total[w][l] = 0;
+        }
+    }
+    // ---- load, wasted bits, constant test
+    int32_t v[kRun];
+    uint32_t ored = 0, neq = 0;
+    const int32_t first = cand_sample(src, 0, C, B, (int)cand, stereo4);
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const uint32_t i = t + (uint32_t)j * NT;
+        v[j] = 0;
+        if (i < bs) {
+            v[j] = cand_sample(src, i, C, B, (int)cand, stereo4);
+            ored |= (uint32_t)v[j];
+            neq |= (uint32_t)(v[j] ^ first);
+        }
+    }
+    __syncthreads();
+    ored = wave_or(ored); neq = wave_or(neq);
+    if (lane == 0) { if (ored) atomicOr(&S.ored, ored); if (neq) atomicOr(&S.neq, neq); }
+    __syncthreads();
+    int wasted = S.ored ? __ffs((int)S.ored) - 1 : 0;
+    if (wasted >= cbps) wasted = cbps - 1;
+    const int sb = cbps - wasted;
+    const uint32_t hdr = 8 + (uint32_t)wasted;
+    if (S.neq == 0) {
+        if (t == 0) {
+            PlanHead h = {};
+            h.bits = hdr + (uint32_t)sb; h.type = 0; h.wasted = (uint8_t)wasted; h.sb = (uint8_t)sb;
+            *reinterpret_cast<PlanHead *>(plan) = h;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) xs[M + t + (uint32_t)j * NT] = v[j] >> wasted;
+    if (t < (uint32_t)M) xs[t] = 0;
+    __syncthreads();
+
+    const uint32_t i0 = t * kRun;
+    // ---- fixed predictors: sums of absolute errors of orders 0..4 over samples 4 .. bs-1
+    {
+        int32_t w[4 + kRun];
+#pragma unroll
+        for (int m = 0; m < 4 + kRun; ++m) w[m] = xs[M + i0 - 4 + m];
+        uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = i0 + j;
+            if (i >= 4 && i < bs) {
+                const int32_t a = w[4 + j], b = w[3 + j], c = w[2 + j], d = w[1 + j], e = w[j];
+                const int32_t d1 = a - b, d2 = a - 2 * b + c, d3 = a - 3 * b + 3 * c - d, d4 = a - 4 * b + 6 * c - 4 * d + e;
+                e0 += (uint32_t)(a < 0 ? -a : a); e1 += (uint32_t)(d1 < 0 ? -d1 : d1); e2 += (uint32_t)(d2 < 0 ? -d2 : d2);
+                e3 += (uint32_t)(d3 < 0 ? -d3 : d3); e4 += (uint32_t)(d4 < 0 ? -d4 : d4);
+            }
+        }
+        e0 = wave_sum64(e0); e1 = wave_sum64(e1); e2 = wave_sum64(e2); e3 = wave_sum64(e3); e4 = wave_sum64(e4);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&S.e[0], (unsigned long long)e0);
+            atomicAdd((unsigned long long *)&S.e[1], (unsigned long long)e1);
+            atomicAdd((unsigned long long *)&S.e[2], (unsigned long long)e2);
+            atomicAdd((unsigned long long *)&S.e[3], (unsigned long long)e3);
+            atomicAdd((unsigned long long *)&S.e[4], (unsigned long long)e4);
+        }
+    }
+    // ---- windowed autocorrelation, lags 0..maxo
+    uint32_t maxo = o.force_lpc_order ? o.force_lpc_order : o.max_lpc_order;
+    if (maxo > (uint32_t)M) maxo = M;
+    const bool try_lpc = maxo > 0 && bs > maxo;
+    if (try_lpc) {
+        double own[kRun];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = i0 + j;
+            const float wv = i < bs ? win[i] : 0.0f;
+            own[j] = (double)((float)xs[M + i] * wv);
+        }
+        constexpr int LG = M <= 12 ? 13 : 17;
+#pragma unroll 1
+        for (int base = 0; base <= (int)maxo; base += LG) {
+            double acc[LG];
+#pragma unroll
+            for (int l = 0; l < LG; ++l) acc[l] = 0.0;
+            // window element m is sample i0 - (base + LG - 1) + m; it meets own[j] at lag base + LG - 1 + j - m
+#pragma unroll
+            for (int m = 0; m < LG - 1 + kRun; ++m) {
+                const int32_t idx = (int32_t)i0 - (base + LG - 1) + m;
+                double d = 0.0;
+                if (idx >= 0 && (uint32_t)idx < bs) d = (double)((float)xs[M + idx] * win[idx]);
+#pragma unroll
+                for (int j = 0; j < kRun; ++j) {
+                    const int l = LG - 1 + j - m;   // lag within the group
+                    if (l >= 0 && l < LG) acc[l] = __fma_rn(own[j], d, acc[l]);
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < LG; ++l) {
+                const double wsum = wave_butterfly(acc[l]);
+                if (lane == 0) S.wsum[wave][l] = wsum;
+            }
+            __syncthreads();
+            if (t < (uint32_t)LG && base + t <= maxo) {
+                double total = S.wsum[0][t];
+                for (int w = 1; w < NT / 64; ++w) total = total + S.wsum[w][t];
+                S.ac[base + t] = total;
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+    // ---- predictor design by one thread
+    if (t == 0) {
+        int fo = 0;
+        for (int k = 1; k <= 4; ++k) if (S.e[k] < S.e[fo]) fo = k;
+        if ((uint32_t)fo > bs) fo = (int)bs;
+        S.fo = fo;
+        if (try_lpc) design_predictor<NT>(S, o, bs, sb, stream_bps, maxo);
+    }
+    __syncthreads();
+
+    // ---- residuals of both predictors
+    const int fo = S.fo, lpc_ok = S.lpc_ok, ord = S.ord;
+    uint32_t uf[kRun], ul[kRun];
+    {
+        int32_t w[M + kRun];
+#pragma unroll
+        for (int m = 0; m < M + kRun; ++m) w[m] = xs[i0 + m];
+        if (lpc_ok) {
+            int32_t cq[M];
+#pragma unroll
+            for (int q = 0; q < M; ++q) cq[q] = S.q[q];
+            uint32_t bad;
+            if (S.wide) bad = lpc_residual<M, 2>(w, cq, S.shift, ul);
+            else if (sb <= 24) bad = lpc_residual<M, 0>(w, cq, S.shift, ul);
+            else bad = lpc_residual<M, 1>(w, cq, S.shift, ul);
+            // only residuals that will be coded count
+            if (bad) {
+                uint32_t coded = 0;
+#pragma unroll
+                for (int j = 0; j < kRun; ++j) {
+                    const uint32_t i = i0 + j;
+                    if (i >= (uint32_t)ord && i < bs) coded |= 1u << j;
+                }
+                if (bad & coded) atomicOr(&S.lpc_bad, 1u);
+            }
+        }
+        fixed_residual<M>(w, fo, uf);
+    }
+    {
+        uint64_t sf = 0, sl = 0;
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = i0 + j;
+            if (i >= (uint32_t)fo && i < bs) sf += uf[j];
+            if (lpc_ok && i >= (uint32_t)ord && i < bs) sl += ul[j];
+        }
+        S.psum[0][t] = sf;
+        S.psum[1][t] = sl;
+    }
+    __syncthreads();
+    const bool use_lpc_search = lpc_ok && !S.lpc_bad;
+    rice_search<NT>(S, o, 0, bs, (uint32_t)fo, uf);
+    if (use_lpc_search) rice_search<NT>(S, o, 1, bs, (uint32_t)ord, ul);
+    __syncthreads();
+
+    // ---- choice and plan
+    const uint32_t pbits0 = S.method[0] ? 5 : 4, pbits1 = S.method[1] ? 5 : 4;
+    const uint32_t fixed_bits = hdr + (uint32_t)fo * (uint32_t)sb + 6 + (pbits0 << S.po[0]) + S.exact[0];
+    uint32_t lpc_bits = 0xFFFFFFFFu;
+    if (use_lpc_search)
+        lpc_bits = hdr + (uint32_t)ord * (uint32_t)sb + 9 + (uint32_t)ord * (uint32_t)S.prec + 6 + (pbits1 << S.po[1]) + S.exact[1];
+    const uint32_t verb_bits = hdr + bs * (uint32_t)sb;
+    int type = 2, which = 0;
+    uint32_t bits = fixed_bits;
+    if (use_lpc_search && (lpc_bits < fixed_bits || o.force_lpc_order)) { type = 3; which = 1; bits = lpc_bits; }
+    if (verb_bits < bits && !o.force_lpc_order) { type = 1; bits = verb_bits; }
+    if (t == 0) {
+        PlanHead h = {};
+        h.bits = bits; h.type = (uint8_t)type; h.wasted = (uint8_t)wasted; h.sb = (uint8_t)sb;
+        h.order = (uint8_t)(type == 3 ? ord : type == 2 ? fo : 0);
+        h.prec = (uint8_t)(type == 3 ? S.prec : 0); h.shift = (uint8_t)(type == 3 ? S.shift : 0);
+        h.po = (uint8_t)S.po[which]; h.method = (uint8_t)S.method[which];
+        *reinterpret_cast<PlanHead *>(plan) = h;
+    }
+    if (type == 3 && t < 32) reinterpret_cast<int16_t *>(plan + kPlanHeadBytes)[t] = (int16_t)S.q[t];
+    if (type >= 2) {
+        const uint32_t np = 1u << S.po[which];
+        for (uint32_t p = t; p < np; p += NT) plan[kPlanHeadBytes + kPlanCoefBytes + p] = S.kb[which][np + p];
+    }
+}
+
+// ------------------------------------------------------------------- layout ---
+
+__device__ inline uint32_t crc8_byte(uint32_t c, uint32_t byte)
+{
+    c ^= byte;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c = (c & 0x80) ? ((c << 1) ^ 0x07) & 0xFF : (c << 1) & 0xFF;
+    return c;
+}
+
+// Header of a fixed-blocksize frame.  Returns its length in bytes (CRC-8 included).
+__device__ inline uint32_t build_frame_header(uint8_t *hp, uint32_t bs, uint32_t sample_rate, uint32_t bps, uint32_t ch_assign,
+                                              uint64_t number)
+{
+    uint32_t n = 0;
+    hp[n++] = 0xFF;
+    hp[n++] = 0xF8;
+    uint32_t bs_code, bs_extra = 0;
+    if (bs == 192) bs_code = 1;
+    else if (bs == 576 || bs == 1152 || bs == 2304 || bs == 4608) bs_code = 2 + (uint32_t)ilog2_32(bs / 576);
+    else if (bs >= 256 && bs <= 32768 && (bs & (bs - 1)) == 0) bs_code = 8 + (uint32_t)ilog2_32(bs / 256);
+    else if (bs <= 256) { bs_code = 6; bs_extra = 1; }
+    else { bs_code = 7; bs_extra = 2; }
+    const uint32_t rates[12] = {0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000};
+    uint32_t sr_code = 0;
+    for (uint32_t i = 1; i < 12; ++i) if (rates[i] == sample_rate) sr_code = i;
+    hp[n++] = (uint8_t)((bs_code << 4) | sr_code);
+    const uint32_t ss = bps == 8 ? 1 : bps == 12 ? 2 : bps == 16 ? 4 : bps == 20 ? 5 : bps == 24 ? 6 : 0;
+    hp[n++] = (uint8_t)((ch_assign << 4) | (ss << 1));
+    if (number < 0x80) hp[n++] = (uint8_t)number;
+    else {
+        const uint32_t len = number < 0x800 ? 2 : number < 0x10000 ? 3 : number < 0x200000 ? 4 : number < 0x4000000 ? 5
+                             : number < 0x80000000ull ? 6 : 7;
+        const uint8_t lead[8] = {0, 0, 0xC0, 0xE0, 0xF0, 0xF8, 0xFC, 0xFE};
+        uint64_t v = number;
+        for (uint32_t i = len - 1; i > 0; --i) { hp[n + i] = (uint8_t)(0x80 | (v & 0x3F)); v >>= 6; }
+        hp[n] = (uint8_t)(lead[len] | v);
+        n += len;
+    }
+    if (bs_extra == 1) hp[n++] = (uint8_t)(bs - 1);
+    if (bs_extra == 2) { hp[n++] = (uint8_t)((bs - 1) >> 8); hp[n++] = (uint8_t)(bs - 1); }
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < n; ++i) c = crc8_byte(c, hp[i]);
+    hp[n++] = (uint8_t)c;
+    return n;
+}
+
+// Zeroes the part of 32-bit word `word` of `out` that lies inside [lo, hi).
+__device__ inline void zero_word_clipped(uint8_t *out, uint64_t word, uint64_t lo, uint64_t hi)
+{
+    const uint64_t a = word * 4;
+    if (a >= lo && a + 4 <= hi) { *reinterpret_cast<uint32_t *>(out + a) = 0; return; }
+    for (uint32_t b = 0; b < 4; ++b)
+        if (a + b >= lo && a + b < hi) out[a + b] = 0;
+}
+
+// One workgroup per stream: frame decisions, sizes, offsets, headers, STREAMINFO.
+__global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ streams, EncOptsDev o, const uint8_t *__restrict__ plans,
+                                                    FrameRec *__restrict__ frames, uint64_t *__restrict__ crc_off,
+                                                    uint32_t *__restrict__ crc_len, uint8_t *__restrict__ out, int md5_later)
+{
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_min, s_max;
+    __shared__ uint64_t s_carry;
+    EncStreamDev &st = streams[blockIdx.x];
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint32_t nf = st.n_frames, ncand = st.ncand, C = st.channels;
+    if (t == 0) { s_min = 0xFFFFFFFFu; s_max = 0; s_carry = 0; }
+    __syncthreads();
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    for (uint32_t f0 = 0; f0 < nf; f0 += 256) {
+        const uint32_t f = f0 + t;
+        uint32_t bytes = 0;
+        FrameRec fr = {};
+        if (f < nf) {
+            const uint8_t *pl = plans + (uint64_t)(st.unit_begin + f * ncand) * o.plan_stride;
+            uint32_t pb[8];
+            for (uint32_t c = 0; c < ncand; ++c) pb[c] = reinterpret_cast<const PlanHead *>(pl + (uint64_t)c * o.plan_stride)->bits;
+            fr.stream = blockIdx.x;
+            fr.bs = (f + 1 == nf) ? st.tail_bs : o.blocksize;
+            if (ncand == 4) {
+                int mode = o.stereo_mode;
+                if (mode < 0) {
+                    const uint32_t b0 = pb[0] + pb[1], b1 = pb[0] + pb[3], b2 = pb[3] + pb[1], b3 = pb[2] + pb[3];
+                    mode = 0;
+                    uint32_t bb = b0;
+                    if (b1 < bb) { bb = b1; mode = 1; }
+                    if (b2 < bb) { bb = b2; mode = 2; }
+                    if (b3 < bb) { bb = b3; mode = 3; }
+                }
+                fr.cand[0] = mode == 0 || mode == 1 ? 0 : mode == 2 ? 3 : 2;
+                fr.cand[1] = mode == 0 || mode == 2 ? 1 : 3;
+                fr.ch_assign = mode == 0 ? 1 : (uint8_t)(7 + mode);
+            } else {
+                for (uint32_t c = 0; c < C; ++c) fr.cand[c] = (uint8_t)c;
+                fr.ch_assign = (uint8_t)(C - 1);
+            }
+            uint8_t hb[16];
+            fr.hdr_len = (uint8_t)build_frame_header(hb, fr.bs, st.sample_rate, st.bps, fr.ch_assign, f);
+            uint32_t bit = 8u * fr.hdr_len;
+            for (uint32_t c = 0; c < C; ++c) { fr.sf_bit[c] = bit; bit += pb[fr.cand[c]]; }
+            bytes = (bit + 7) / 8 + 2;
+            fr.bytes = bytes;
+            mn = bytes < mn ? bytes : mn;
+            mx = bytes > mx ? bytes : mx;
+        }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan<256>(bytes, s_w, total);
+        if (f < nf) {
+            fr.out_off = st.out_off + 42 + s_carry + excl;
+            frames[st.frame_begin + f] = fr;
+        }
+        __syncthreads();
+        if (t == 0) s_carry += total;
+        __syncthreads();
+    }
+    mn = wave_min32(mn); mx = wave_max32(mx);
+    if (lane == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    __syncthreads();
+    const uint64_t out_len = 42 + s_carry;
+    const bool fits = out_len <= st.out_cap;
+    if (t == 0) {
+        st.out_len = out_len;
+        st.min_fs = nf ? s_min : 0;
+        st.max_fs = s_max;
+        st.status = fits ? 0 : 8;   // FLACGPU_ERR_CAPACITY
+        if (fits) {
+            // marker, block header (flacmeta.go:519-551) and STREAMINFO (flacmeta.go:644-717)
+            uint8_t *p = out + st.out_off;
+            p[0] = 'f'; p[1] = 'L'; p[2] = 'a'; p[3] = 'C';
+            p[4] = 0x80; p[5] = 0; p[6] = 0; p[7] = 34;
+            uint8_t *s = p + 8;
+            const uint32_t Bk = o.blocksize, mnf = st.min_fs, mxf = st.max_fs;
+            s[0] = (uint8_t)(Bk >> 8); s[1] = (uint8_t)Bk; s[2] = (uint8_t)(Bk >> 8); s[3] = (uint8_t)Bk;
+            s[4] = (uint8_t)(mnf >> 16); s[5] = (uint8_t)(mnf >> 8); s[6] = (uint8_t)mnf;
+            s[7] = (uint8_t)(mxf >> 16); s[8] = (uint8_t)(mxf >> 8); s[9] = (uint8_t)mxf;
+            const uint64_t v = ((uint64_t)st.sample_rate << 44) | ((uint64_t)(C - 1) << 41) | ((uint64_t)(st.bps - 1) << 36) |
+                               (st.total_samples & 0xFFFFFFFFFull);
+            for (int k = 0; k < 8; ++k) s[10 + k] = (uint8_t)(v >> (56 - 8 * k));
+            if (!md5_later) for (int k = 0; k < 16; ++k) s[18 + k] = st.md5[k];
+        }
+    }
+    // second pass: clear the words subframes share with their neighbours, write the frame headers
+    for (uint32_t f = t; f < nf; f += 256) {
+        FrameRec &fr = frames[st.frame_begin + f];
+        const uint32_t g = st.frame_begin + f;
+        if (!fits) { fr.bytes = 0; crc_off[g] = 0; crc_len[g] = 0; continue; }
+        const uint64_t lo = fr.out_off, hi = lo + fr.bytes;
+        const uint8_t *pl = plans + (uint64_t)(st.unit_begin + f * ncand) * o.plan_stride;
+        for (uint32_t c = 0; c < C; ++c) {
+            const uint32_t bits = reinterpret_cast<const PlanHead *>(pl + (uint64_t)fr.cand[c] * o.plan_stride)->bits;
+            const uint64_t gs = lo * 8 + fr.sf_bit[c], ge = gs + bits - 1;
+            zero_word_clipped(out, gs >> 5, lo, hi);
+            zero_word_clipped(out, ge >> 5, lo, hi);
+        }
+        uint8_t hb[16];
+        const uint32_t hl = build_frame_header(hb, fr.bs, st.sample_rate, st.bps, fr.ch_assign, f);
+        for (uint32_t i = 0; i < hl; ++i) out[lo + i] = hb[i];
+        crc_off[g] = lo;
+        crc_len[g] = fr.bytes - 2;
+    }
+}
+
+// --------------------------------------------------------------------- pack ---
+
+// ORs `width` (<= 32) bits of value, most significant first, at bit position pos of an LDS bit buffer.
+__device__ inline void put_bits(uint32_t *buf, uint32_t pos, uint32_t value, uint32_t width)
+{
+    if (width == 0) return;
+    const uint32_t w = pos >> 5, sh = pos & 31;
+    const uint64_t v = (uint64_t)value << (64 - width - sh);
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    if (hi) atomicOr(&buf[w], hi);
+    if (lo) atomicOr(&buf[w + 1], lo);
+}
+
+template <int M, int NT>
+__global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
+                                                 uint32_t n_streams, EncOptsDev o, const uint8_t *__restrict__ plans,
+                                                 const FrameRec *__restrict__ frames, uint8_t *__restrict__ out, uint32_t buf_words)
+{
+    extern __shared__ __align__(16) int32_t lds[];   // xs: M + NT * kRun samples, then the bit buffer
+    int32_t *xs = lds;
+    uint32_t *buf = reinterpret_cast<uint32_t *>(lds + M + NT * kRun);
+    __shared__ uint32_t s_w[NT / 64];
+    __shared__ int32_t s_q[32];
+    __shared__ uint8_t s_k[256];
+    const uint32_t t = threadIdx.x;
+    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x);
+    if (unit >= o.total_pack) return;
+    const int si = find_enc_stream(streams, n_streams, unit, 1);
+    const EncStreamDev &st = streams[si];
+    const uint32_t C = st.channels, rel = unit - st.pack_begin;
+    const uint32_t f = rel / C, ch = rel - f * C;
+    const FrameRec &fr = frames[st.frame_begin + f];
+    if (fr.bytes == 0) return;
+    const uint32_t cand = fr.cand[ch], bs = fr.bs, ncand = st.ncand;
+    const uint8_t *plan = plans + (uint64_t)(st.unit_begin + f * ncand + cand) * o.plan_stride;
+    const PlanHead ph = *reinterpret_cast<const PlanHead *>(plan);
+    const int B = st.bytes_ps;
+    const bool stereo4 = ncand == 4;
+    const uint8_t *src = pcm + st.in_off + (uint64_t)f * o.blocksize * (uint32_t)(C * B);
+    const uint64_t G = fr.out_off * 8 + fr.sf_bit[ch];
+    const uint32_t phase = (uint32_t)(G & 31);
+    const uint64_t word0 = G >> 5;
+    const uint32_t nwords = (phase + ph.bits + 31) >> 5;
+    const int wasted = ph.wasted, sb = ph.sb, order = ph.order, type = ph.type;
+    const uint32_t smask = sb >= 32 ? 0xFFFFFFFFu : (1u << sb) - 1;
+
+    for (uint32_t i = t; i < nwords + 1 && i < buf_words; i += NT) buf[i] = 0;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const uint32_t i = t + (uint32_t)j * NT;
+        xs[M + i] = i < bs ? cand_sample(src, i, (int)C, B, (int)cand, stereo4) >> wasted : 0;
+    }
+    if (t < (uint32_t)M) xs[t] = 0;
+    if (t < 32) s_q[t] = type == 3 ? (int32_t)reinterpret_cast<const int16_t *>(plan + kPlanHeadBytes)[t] : 0;
+    if (type >= 2) for (uint32_t p = t; p < (1u << ph.po); p += NT) s_k[p] = plan[kPlanHeadBytes + kPlanCoefBytes + p];
+    __syncthreads();
+
+    uint32_t pos = phase;
+    if (t == 0) {
+        const uint32_t code = type == 0 ? 0 : type == 1 ? 1 : type == 2 ? 8 + (uint32_t)order : 31 + (uint32_t)order;
+        put_bits(buf, pos, (code << 1) | (wasted ? 1u : 0u), 8);
+        if (wasted) put_bits(buf, pos + 8 + (uint32_t)wasted - 1, 1, 1);
+    }
+    pos += 8 + (uint32_t)wasted;
+    const uint32_t i0 = t * kRun;
+    if (type == 0) {
+        if (t == 0) put_bits(buf, pos, (uint32_t)xs[M] & smask, (uint32_t)sb);
+    } else if (type == 1) {
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = i0 + j;
+            if (i < bs) put_bits(buf, pos + i * (uint32_t)sb, (uint32_t)xs[M + i] & smask, (uint32_t)sb);
+        }
+    } else {
+        if (t < (uint32_t)order) put_bits(buf, pos + t * (uint32_t)sb, (uint32_t)xs[M + t] & smask, (uint32_t)sb);
+        pos += (uint32_t)order * (uint32_t)sb;
+        if (type == 3) {
+            const uint32_t prec = ph.prec;
+            if (t == 0) { put_bits(buf, pos, prec - 1, 4); put_bits(buf, pos + 4, ph.shift, 5); }
+            if (t < (uint32_t)order) put_bits(buf, pos + 9 + t * prec, (uint32_t)s_q[t] & ((1u << prec) - 1), prec);
+            pos += 9 + (uint32_t)order * prec;
+        }
+        const uint32_t pbits = ph.method ? 5 : 4;
+        if (t == 0) { put_bits(buf, pos, ph.method, 2); put_bits(buf, pos + 2, ph.po, 4); put_bits(buf, pos + 6, s_k[0], pbits); }
+        pos += 6 + pbits;
+        // residual codes
+        uint32_t u[kRun];
+        {
+            int32_t w[M + kRun];
+#pragma unroll
+            for (int m = 0; m < M + kRun; ++m) w[m] = xs[i0 + m];
+            if (type == 3) {
+                int32_t cq[M];
+#pragma unroll
+                for (int q = 0; q < M; ++q) cq[q] = q < 32 ? s_q[q] : 0;
+                const bool wide = (sb + (int)ph.prec + ilog2_32((uint32_t)order)) > 32;
+                if (wide) (void)lpc_residual<M, 2>(w, cq, ph.shift, u);
+                else if (sb <= 24) (void)lpc_residual<M, 0>(w, cq, ph.shift, u);
+                else (void)lpc_residual<M, 1>(w, cq, ph.shift, u);
+            } else {
+                fixed_residual<M>(w, order, u);
+            }
+        }
+        const uint32_t po = ph.po, psize = bs >> po;
+        const uint32_t part = po ? i0 / psize : 0;
+        const bool starts = po && i0 > 0 && i0 < bs && (i0 - part * psize) == 0;
+        const uint32_t k = s_k[part < (1u << po) ? part : 0];
+        uint32_t mybits = starts ? pbits : 0;
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = i0 + j;
+            if (i >= (uint32_t)order && i < bs) mybits += (u[j] >> k) + k + 1;
+        }
+        uint32_t total;
+        uint32_t at = pos + block_excl_scan<NT>(mybits, s_w, total);
+        if (starts) { put_bits(buf, at, k, pbits); at += pbits; }
+        const uint32_t kmask = (1u << k) - 1;
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = i0 + j;
+            if (i >= (uint32_t)order && i < bs) {
+                const uint32_t q = u[j] >> k;
+                put_bits(buf, at + q, (1u << k) | (u[j] & kmask), k + 1);
+                at += q + k + 1;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    for (uint32_t w = t; w < nwords; w += NT) {
+        const uint32_t val = __builtin_bswap32(buf[w]);
+        if (w == 0 || w + 1 == nwords) { if (val) atomicOr(&out32[word0 + w], val); }
+        else out32[word0 + w] = val;
+    }
+}
+
+__global__ void k_enc_write_crc(const FrameRec *__restrict__ frames, const uint16_t *__restrict__ crc, uint32_t n, uint8_t *__restrict__ out)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const FrameRec &fr = frames[g];
+    if (!fr.bytes) return;
+    const uint32_t c = crc[g];
+    out[fr.out_off + fr.bytes - 2] = (uint8_t)(c >> 8);
+    out[fr.out_off + fr.bytes - 1] = (uint8_t)c;
+}
+
+// ---------------------------------------------------------------------- MD5 ---
+
+__device__ inline uint32_t rol32(uint32_t x, uint32_t s) { return (x << s) | (x >> (32 - s)); }
+
+__device__ inline void md5_block(uint32_t (&h)[4], const uint32_t (&w)[16], const uint32_t *T)
+{
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int r = i >> 4;
+        uint32_t fn;
+        int g;
+        if (r == 0) { fn = d ^ (b & (c ^ d)); g = i; }
+        else if (r == 1) { fn = c ^ (d & (b ^ c)); g = (5 * i + 1) & 15; }
+        else if (r == 2) { fn = b ^ c ^ d; g = (3 * i + 5) & 15; }
+        else { fn = c ^ (b | ~d); g = (7 * i) & 15; }
+        const int rot[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
+        const uint32_t tt = a + fn + T[i] + w[g];
+        a = d; d = c; c = b; b += rol32(tt, (uint32_t)rot[r][i & 3]);
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+}
+
+// MD5 of each stream's packed PCM (the STREAMINFO signature, flacmeta.go:714), one lane per stream.
+// T: the 64 sine-derived constants of RFC 1321.
+__global__ __launch_bounds__(64) void k_enc_md5(const uint8_t *__restrict__ pcm, EncStreamDev *__restrict__ streams, uint32_t n,
+                                                const uint32_t *__restrict__ T, uint8_t *__restrict__ out)
+{
+    __shared__ uint32_t s_T[64];
+    s_T[threadIdx.x] = T[threadIdx.x];
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    EncStreamDev &st = streams[s];
+    const uint64_t len = st.total_samples * st.channels * st.bytes_ps;
+    const uint8_t *p = pcm + st.in_off;
+    uint32_t h[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+    const bool aligned = (((uintptr_t)p) & 15) == 0;
+    uint64_t done = 0;
+    uint32_t w[16];
+    for (; done + 64 <= len; done += 64) {
+        if (aligned) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(p + done + 16 * q);
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint8_t *b = p + done + 4 * q;
+                w[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+            }
+        }
+        md5_block(h, w, s_T);
+    }
+    // tail: remaining bytes, 0x80, zeros, 64-bit length in bits
+    const uint32_t rem = (uint32_t)(len - done);
+    const uint64_t bits = len * 8;
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t idx = (uint32_t)blk * 64 + (uint32_t)q * 4 + (uint32_t)b;
+                uint32_t byte = 0;
+                if (idx < rem) byte = p[done + idx];
+                else if (idx == rem) byte = 0x80;
+                word |= byte << (8 * b);
+            }
+            w[q] = word;
+        }
+        const bool lastblk = (blk == 0 && rem < 56) || blk == 1;
+        if (lastblk) { w[14] = (uint32_t)bits; w[15] = (uint32_t)(bits >> 32); }
+        md5_block(h, w, s_T);
+        if (lastblk) break;
+    }
+    for (int q = 0; q < 4; ++q)
+        for (int b = 0; b < 4; ++b) st.md5[4 * q + b] = (uint8_t)(h[q] >> (8 * b));
+    if (out && st.out_cap >= 42)
+        for (int q = 0; q < 16; ++q) out[st.out_off + 26 + q] = st.md5[q];
+}
+
+}  // namespace flacgpu

@@ -24,63 +24,9 @@
 
 using namespace flacgpu;
 
-namespace {
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-};
-
-enum { EV_START, EV_SCAN, EV_COMPACT, EV_CRC, EV_RESOLVE, EV_SKIM, EV_DECODE, EV_RESULTS, EV_COUNT };
-
-}  // namespace
-
-struct flacgpu_handle {
-    int device = 0;
-    uint32_t flags = 0;
-    hipStream_t own_stream = nullptr;
-    std::string err;
-    DevBuf streams, results, mask, bitmap, tile_count, tile_base, group_sum, group_base, counter, crc_tables;
-    DevBuf goff, num, info, stream, len, status, segcrc, seglen, subpos, next;
-    uint32_t cand_cap = 0;
-    hipEvent_t ev[EV_COUNT] = {};
-    flacgpu_timing timing = {};
-    std::vector<StreamDev> h_streams;
-    // state of the last scan, used by flacgpu_scan_frames
-    uint32_t n_cand = 0;
-};
+#include "handle.hpp"
 
 namespace {
-
-int fail(flacgpu_handle *h, int code, const std::string &msg)
-{
-    if (h) h->err = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(h, e_ == hipErrorOutOfMemory ? FLACGPU_ERR_NOMEM : FLACGPU_ERR_DEVICE, \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
-    } while (0)
-
-int reserve(flacgpu_handle *h, DevBuf &b, size_t bytes)
-{
-    if (b.bytes >= bytes) return FLACGPU_OK;
-    if (b.p) { HIP_TRY(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
-    size_t want = bytes + bytes / 8 + 256;
-    HIP_TRY(hipMalloc(&b.p, want));
-    b.bytes = want;
-    return FLACGPU_OK;
-}
-
-void release(DevBuf &b)
-{
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr; b.bytes = 0;
-}
 
 CandArrays cand_arrays(flacgpu_handle *h)
 {
@@ -244,6 +190,22 @@ void collect_timing(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes)
 
 }  // namespace
 
+namespace flacgpu {
+
+void launch_crc16_spans(flacgpu_handle *h, const uint8_t *base, const uint64_t *off, const uint32_t *len, uint16_t *crc,
+                        uint32_t n, hipStream_t st)
+{
+    if (!n) return;
+    CandArrays c = {};
+    c.goff = const_cast<uint64_t *>(off);
+    c.seglen = const_cast<uint32_t *>(len);
+    c.segcrc = crc;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 3) / 4, 256 * 8);
+    k_crc16_spans<<<blocks, 256, 0, st>>>(base, c, n, (const uint16_t *)h->crc_tables.p);
+}
+
+}  // namespace flacgpu
+
 extern "C" {
 
 int flacgpu_create(const flacgpu_options *opts, flacgpu_handle **out)
@@ -275,6 +237,7 @@ void flacgpu_destroy(flacgpu_handle *h)
                      &h->counter, &h->crc_tables, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
                      &h->seglen, &h->subpos, &h->next};
     for (DevBuf *b : all) release(*b);
+    encode_release(h);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

@@ -227,6 +227,92 @@ int flacgpu_decode_batch(flacgpu_handle *h, const uint8_t *const *bufs, const ui
 
 int flacgpu_get_timing(const flacgpu_handle *h, flacgpu_timing *out);
 
+/* ------------------------------------------------------------ encoder (GPU) */
+
+/* The reference has no encoder; these entry points are what a cgo binding of
+ * `package flac` would declare for the write side.  What they must agree with
+ * in the reference is the layout of what they write in front of the frames:
+ * the "fLaC" marker (flacmeta.go:754-761), one block header (flacmeta.go:519-551,
+ * last = 1, type STREAMINFO, length 34) and the STREAMINFO block exactly as
+ * MarshalStreaminfoBlock reads it (flacmeta.go:644-717), so that
+ * (*Metadata).Read on the output leaves the reader on frame 0. */
+
+typedef struct flacgpu_encode_options {
+    uint32_t struct_size;          /* sizeof(flacgpu_encode_options)                               */
+    uint32_t blocksize;            /* inter-channel samples per frame, 16..16384                   */
+    uint32_t max_lpc_order;        /* 0 (fixed predictors only) .. 32                              */
+    uint32_t qlp_precision;        /* bits per LPC coefficient 5..15; 0 = by sample size and block */
+    uint32_t min_partition_order;  /* Rice partition order range, 0..8; min == max forces it       */
+    uint32_t max_partition_order;
+    int32_t  stereo_mode;          /* -1 cheapest per frame, 0 left/right, 1 left/side, 2 side/right, 3 mid/side */
+    uint32_t force_lpc_order;      /* 0 = estimate the order per subframe; else exactly this order */
+    uint32_t flags;                /* FLACGPU_ENC_*                                                */
+    uint32_t reserved;
+} flacgpu_encode_options;
+
+#define FLACGPU_ENC_MD5 1u   /* hash the PCM on the device for STREAMINFO (one lane per stream) */
+
+/* One stream to encode.  All PCM of a batch lives in ONE device buffer (d_pcm) as
+ * interleaved signed little-endian samples of ceil(bps/8) bytes: the byte string
+ * the STREAMINFO MD5 is defined over and the decoder writes.  in_offset must be a
+ * multiple of 4.  The complete .flac stream goes to d_out + out_offset. */
+typedef struct flacgpu_pcm_stream {
+    uint64_t in_offset;
+    uint64_t total_samples;    /* inter-channel samples (StreaminfoBlock.TotalSamples, flacmeta.go:662) */
+    uint64_t out_offset;       /* multiple of 4 */
+    uint64_t out_capacity;     /* see flacgpu_encode_bound */
+    uint32_t sample_rate;
+    uint8_t  channels;         /* 1..8 */
+    uint8_t  bits_per_sample;  /* 4..24 */
+    uint8_t  reserved[2];
+    uint8_t  md5[16];          /* stored in STREAMINFO unless FLACGPU_ENC_MD5 is set; zeros = not computed */
+} flacgpu_pcm_stream;
+
+typedef struct flacgpu_encode_result {
+    uint64_t out_length;       /* bytes of the .flac stream (42 + frames), also when it did not fit */
+    uint64_t frames;
+    uint32_t min_framesize;
+    uint32_t max_framesize;
+    int32_t  status;           /* FLACGPU_OK, or FLACGPU_ERR_CAPACITY: nothing usable was written  */
+    uint32_t reserved;
+    uint8_t  md5[16];          /* as stored in STREAMINFO */
+} flacgpu_encode_result;
+
+/* Device time of the last encode call, milliseconds (FLACGPU_FLAG_TIMING). */
+typedef struct flacgpu_encode_timing {
+    float analyze_ms;    /* predictor search per candidate channel                    */
+    float layout_ms;     /* stereo decisions, frame sizes and offsets, headers        */
+    float pack_ms;       /* residual coding and bit packing                           */
+    float crc_ms;        /* CRC-16 of every frame                                     */
+    float md5_ms;        /* runs beside the other stages on a second stream           */
+    float total_ms;      /* first kernel to last kernel of the main stream            */
+    uint64_t frames;
+    uint64_t in_bytes;   /* PCM bytes encoded                                         */
+    uint64_t out_bytes;  /* .flac bytes produced                                      */
+} flacgpu_encode_timing;
+
+/* Largest possible size of one encoded stream: a capacity that always fits. */
+uint64_t flacgpu_encode_bound(uint64_t total_samples, uint32_t channels, uint32_t bits_per_sample, uint32_t blocksize);
+
+/* Encodes a device-resident batch into complete .flac streams (marker,
+ * STREAMINFO, fixed-blocksize frames).  d_pcm / d_out: device pointers, 16-byte
+ * aligned, each readable up to the next multiple of 16 bytes.  Returns when the
+ * work is complete; a stream that does not fit its capacity gets
+ * FLACGPU_ERR_CAPACITY in its result and does not fail the call. */
+int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t pcm_bytes,
+                                void *d_out, uint64_t out_bytes,
+                                const flacgpu_pcm_stream *streams, uint32_t n_streams,
+                                const flacgpu_encode_options *opts,
+                                flacgpu_encode_result *results, void *hip_stream);
+
+/* Host-buffer convenience: pcm[i] -> out[i] (out_caps[i] bytes), copies over PCIe
+ * around flacgpu_encode_batch_device.  streams[i].in_offset / out_offset are ignored. */
+int flacgpu_encode_batch(flacgpu_handle *h, const uint8_t *const *pcm, const flacgpu_pcm_stream *streams,
+                         uint32_t n_streams, const flacgpu_encode_options *opts,
+                         uint8_t *const *out, const uint64_t *out_caps, flacgpu_encode_result *results);
+
+int flacgpu_get_encode_timing(const flacgpu_handle *h, flacgpu_encode_timing *out);
+
 #ifdef __cplusplus
 }
 #endif

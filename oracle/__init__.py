@@ -14,8 +14,8 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "flac_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("flac_oracle.c", "flac_enc_oracle.c", "flac_oracle.h", "flac_enc_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
     return _LIB
 
@@ -60,6 +60,20 @@ class Stats(ctypes.Structure):
     ]
 
 
+class EncOpts(ctypes.Structure):
+    """orc_enc_opts: the fields of flacgpu_encode_options the algorithm reads."""
+    _fields_ = [
+        ("blocksize", ctypes.c_uint32),
+        ("max_lpc_order", ctypes.c_uint32),
+        ("qlp_precision", ctypes.c_uint32),
+        ("min_partition_order", ctypes.c_uint32),
+        ("max_partition_order", ctypes.c_uint32),
+        ("stereo_mode", ctypes.c_int32),
+        ("force_lpc_order", ctypes.c_uint32),
+        ("flags", ctypes.c_uint32),
+    ]
+
+
 _lib = None
 
 
@@ -85,6 +99,13 @@ def lib():
                                        ctypes.POINTER(StreamInfo), ctypes.c_uint32, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.POINTER(Stats), ctypes.c_int]
+        L.orc_enc_window.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
+        L.orc_encode_bound.restype = ctypes.c_uint64
+        L.orc_encode_bound.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+        L.orc_encode_stream.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                                        ctypes.POINTER(EncOpts), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint64),
+                                        ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -159,3 +180,36 @@ def decode_batch(data: np.ndarray, offs, lens, infos, pcm: np.ndarray, pcm_offs,
     if rc:
         raise RuntimeError(f"orc_decode_batch: status {rc}")
     return pcm_lens, [stats[i] for i in range(n)]
+
+
+def enc_options(blocksize=4096, max_lpc_order=12, qlp_precision=0, min_partition_order=0, max_partition_order=6,
+                stereo_mode=-1, force_lpc_order=0, flags=0) -> EncOpts:
+    return EncOpts(blocksize, max_lpc_order, qlp_precision, min_partition_order, max_partition_order, stereo_mode,
+                   force_lpc_order, flags)
+
+
+def encode_window(bs: int) -> np.ndarray:
+    w = np.empty(bs, dtype=np.float32)
+    lib().orc_enc_window(bs, w.ctypes.data)
+    return w
+
+
+def encode_bound(total_samples, channels, bps, blocksize) -> int:
+    return int(lib().orc_encode_bound(total_samples, channels, bps, blocksize))
+
+
+def encode_stream(pcm, total_samples, channels, bps, sample_rate, opts: EncOpts, md5: bytes = None):
+    """pcm: packed interleaved little-endian samples (bytes-like).  Returns (file bytes as np.uint8,
+    frames, min_framesize, max_framesize)."""
+    a = np.ascontiguousarray(np.frombuffer(pcm, dtype=np.uint8))
+    assert a.size == total_samples * channels * ((bps + 7) // 8)
+    cap = encode_bound(total_samples, channels, bps, opts.blocksize)
+    out = np.zeros(cap, dtype=np.uint8)
+    n, nf, mn, mx = ctypes.c_size_t(), ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32()
+    m = (ctypes.c_uint8 * 16)(*md5) if md5 is not None else None
+    rc = lib().orc_encode_stream(a.ctypes.data, total_samples, channels, bps, sample_rate, ctypes.byref(opts), m,
+                                 out.ctypes.data, cap, ctypes.byref(n), ctypes.byref(nf), ctypes.byref(mn),
+                                 ctypes.byref(mx))
+    if rc:
+        raise RuntimeError(f"orc_encode_stream: status {rc}")
+    return out[: n.value].copy(), nf.value, mn.value, mx.value

@@ -1,0 +1,76 @@
+"""CPU tests of the encoder oracle (oracle/flac_enc_oracle.c): what it writes must decode, with the
+decoder oracle (pinned by the reference's fixtures) and with the independent Python decoder, to the
+source PCM, and its STREAMINFO must read back through the product's restatement of
+MarshalStreaminfoBlock (flacmeta.go:644-717)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from enc_cases import ENC_GROUPS, SPECIAL_KINDS, special_pcm
+from util import flac_amd, make_pcm_group, oracle, oracle_decode, split_file, synth
+import pydecoder
+
+
+def _check_file(f, packed, shape, opts):
+    n, rate, ch, bps = shape
+    md = flac_amd.parse_metadata(bytes(f))
+    assert md.first_frame_offset == 42 and md.n_blocks == 1 and md.blocks[0].last == 1
+    si = md.streaminfo
+    assert (si.min_blocksize, si.max_blocksize) == (opts.blocksize, opts.blocksize)
+    assert (si.sample_rate, si.channels, si.bits_per_sample, si.total_samples) == (rate, ch, bps, n)
+    assert si.md5_signature == hashlib.md5(packed).hexdigest()
+    si2, audio = split_file(bytes(f))
+    pcm, st = oracle_decode(si2, audio)
+    assert bytes(pcm) == packed
+    frames, _ = oracle.scan_frames(audio, oracle.parse_streaminfo(bytes(f[8:42])))
+    sizes = [fr.length for fr in frames]
+    assert len(frames) == (n + opts.blocksize - 1) // opts.blocksize == st.frames_ok
+    if sizes:
+        assert (min(sizes), max(sizes)) == (si.min_framesize, si.max_framesize)
+    assert len(f) == 42 + sum(sizes)
+
+
+@pytest.mark.parametrize("group", ENC_GROUPS, ids=[g["name"] for g in ENC_GROUPS])
+def test_oracle_encoder_round_trip(group):
+    opts = oracle.enc_options(**group["opts"])
+    for x, packed, shape in make_pcm_group(group):
+        n, rate, ch, bps = shape
+        f, nf, mn, mx = oracle.encode_stream(packed, n, ch, bps, rate, opts)
+        _check_file(f, packed, shape, opts)
+        assert len(f) <= oracle.encode_bound(n, ch, bps, opts.blocksize)
+
+
+@pytest.mark.parametrize("kind", SPECIAL_KINDS)
+def test_oracle_encoder_special_signals(kind):
+    rng = np.random.default_rng(11)
+    opts = oracle.enc_options(blocksize=1024, max_lpc_order=12, max_partition_order=6)
+    for ch, bps in ((2, 16), (1, 24), (2, 8)):
+        n = 1024 * 3 + 333
+        x = special_pcm(kind, n, ch, bps, rng)
+        packed = synth.pack_pcm(x, bps)
+        f, nf, mn, mx = oracle.encode_stream(packed, n, ch, bps, 44100, opts)
+        _check_file(f, packed, (n, 44100, ch, bps), opts)
+        if kind in ("silence", "constant"):
+            assert len(f) < 42 + 4 * 32
+        if kind == "noise":
+            assert len(f) <= oracle.encode_bound(n, ch, bps, 1024)
+
+
+def test_oracle_encoder_python_decoder_agrees():
+    """The independent pure-Python decoder reads the encoder oracle's LPC / fixed / mid-side output."""
+    x = synth.pcm(42, 2 * 576 + 50, 2, 16, 44100, 576)
+    packed = synth.pack_pcm(x, 16)
+    f, _, _, _ = oracle.encode_stream(packed, x.shape[0], 2, 16, 44100, oracle.enc_options(576, 8, max_partition_order=3))
+    _, got = pydecoder.decode_file(bytes(f))
+    assert got == packed
+
+
+def test_oracle_encoder_compresses_like_the_corpus_encoder():
+    """Same predictor family as the corpus generator's encoder: sizes within 1 %."""
+    x = synth.pcm(1, 4096 * 6, 2, 16, 44100, 4096)
+    packed = synth.pack_pcm(x, 16)
+    f, _, _, _ = oracle.encode_stream(packed, x.shape[0], 2, 16, 44100, oracle.enc_options(4096, 12))
+    g, _ = synth.encode(x, 16, 44100, synth.options(4096, 12))
+    assert abs(len(f) - len(g)) <= 0.01 * len(g)
+    assert len(f) < 0.7 * len(packed)

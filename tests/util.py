@@ -80,3 +80,51 @@ def make_file(idx, nsamples, channels=2, bps=16, rate=44100, blocksize=4096, max
 
 def md5hex(a) -> str:
     return hashlib.md5(bytes(a)).hexdigest()
+
+
+def make_pcm_group(group, seed=7):
+    """Source PCM of one encoder test group: list of (int32 samples [n, ch], packed bytes, (n, rate, ch, bps))."""
+    out = []
+    for i, (ch, bps, rate, n) in enumerate(group["streams"]):
+        x = synth.pcm(seed * 100 + i, n, ch, bps, rate, group["opts"]["blocksize"])
+        out.append((x, synth.pack_pcm(x, bps), (n, rate, ch, bps)))
+    return out
+
+
+def gpu_encode_group(engine, packed, shapes, opts, cap_scale=1.0, md5s=None):
+    """Encodes packed PCM byte strings with the device-resident entry point.
+    Returns (list of .flac byte strings or None where the stream did not fit, results)."""
+    import torch
+    in_offs, out_offs, caps = [], [], []
+    pos = 0
+    for p in packed:
+        in_offs.append(pos)
+        pos += (len(p) + 255) // 256 * 256
+    pcm_bytes = pos + 256
+    pos = 0
+    for (n, rate, ch, bps) in shapes:
+        cap = int(flac_amd.encode_bound(n, ch, bps, opts.blocksize) * cap_scale)
+        caps.append(cap)
+        out_offs.append(pos)
+        pos += (cap + 255) // 256 * 256
+    out_bytes = pos + 256
+    host = np.zeros(pcm_bytes, dtype=np.uint8)
+    for p, o in zip(packed, in_offs):
+        host[o:o + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    d_pcm = torch.from_numpy(host).cuda()
+    d_out = torch.full((out_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
+    streams = engine.make_pcm_streams(
+        (in_offs[i], shapes[i][0], out_offs[i], caps[i], shapes[i][1], shapes[i][2], shapes[i][3],
+         md5s[i] if md5s else None) for i in range(len(packed)))
+    res = engine.encode_batch_device(d_pcm, pcm_bytes, d_out, out_bytes, streams, opts)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    files = []
+    for i, r in enumerate(res):
+        files.append(bytes(out[out_offs[i]: out_offs[i] + int(r.out_length)]) if r.status == 0 else None)
+    # nothing outside a stream's capacity may be touched
+    for i in range(len(packed)):
+        end = out_offs[i] + caps[i]
+        nxt = out_offs[i + 1] if i + 1 < len(packed) else out_bytes
+        assert np.all(out[end:nxt] == 0x5A), f"stream {i}: bytes beyond its capacity were written"
+    return files, list(res)
