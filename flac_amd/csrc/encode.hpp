@@ -463,7 +463,7 @@ __global__ __launch_bounds__(NT) void k_enc_analyze(const uint8_t *__restrict__ 
     const uint32_t bs = last ? st.tail_bs : o.blocksize;
     const float *win = windows + (last ? st.win_off_tail : st.win_off);
     const int C = st.channels, B = st.bytes_ps, stream_bps = st.bps;
-    const bool stereo4 = ncand == 4;
+    const bool stereo4 = C == 2;
     const int cbps = stream_bps + (stereo4 && cand == 3 ? 1 : 0);
     const uint8_t *src = pcm + st.in_off + (uint64_t)f * o.blocksize * (uint32_t)(C * B);
     uint8_t *plan = plans + (uint64_t)unit * o.plan_stride;
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
             for (uint32_t c = 0; c < ncand; ++c) pb[c] = reinterpret_cast<const PlanHead *>(pl + (uint64_t)c * o.plan_stride)->bits;
             fr.stream = blockIdx.x;
             fr.bs = (f + 1 == nf) ? st.tail_bs : o.blocksize;
-            if (ncand == 4) {
+            if (C == 2) {
                 int mode = o.stereo_mode;
                 if (mode < 0) {
                     const uint32_t b0 = pb[0] + pb[1], b1 = pb[0] + pb[3], b2 = pb[3] + pb[1], b3 = pb[2] + pb[3];
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
     const uint8_t *plan = plans + (uint64_t)(st.unit_begin + f * ncand + cand) * o.plan_stride;
     const PlanHead ph = *reinterpret_cast<const PlanHead *>(plan);
     const int B = st.bytes_ps;
-    const bool stereo4 = ncand == 4;
+    const bool stereo4 = C == 2;
     const uint8_t *src = pcm + st.in_off + (uint64_t)f * o.blocksize * (uint32_t)(C * B);
     const uint64_t G = fr.out_off * 8 + fr.sf_bit[ch];
     const uint32_t phase = (uint32_t)(G & 31);
