@@ -34,6 +34,65 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def encode_leg(args, eng, dev, rank, world, d_in, d_pcm, pcm_stride, nfiles, nsamples, channels, bps, rate, blocksize,
+               pcm_bytes_per_file, infos, unique, hip_stream, threads):
+    """Encodes the decoded batch back to FLAC on the device (flacgpu_encode_batch_device) and reports its
+    throughput; checks sampled streams by decoding them with the CPU oracle against the source MD5."""
+    import hashlib
+    import torch
+    import flac_amd
+    cap = int(pcm_bytes_per_file * 0.80) // 256 * 256 + 4096     # per-stream output capacity (synthetic ratio is 0.58-0.76)
+    out_bytes = cap * nfiles + 256
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    need = out_bytes + nfiles * ((nsamples + blocksize - 1) // blocksize) * (4 * 176 + 96) + (2 << 30)
+    if free_b + d_in.numel() < need:
+        log(f"encode leg skipped: needs {need / 1e9:.0f} GB, {free_b / 1e9:.0f} GB free")
+        return None
+    d_enc = d_in if d_in.numel() >= out_bytes else torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+    opts = flac_amd.encode_options(blocksize=blocksize, max_lpc_order=args.lpc_order,
+                                   max_partition_order=(args.force_partition_order if args.force_partition_order >= 0
+                                                        else args.partition_order),
+                                   min_partition_order=max(0, args.force_partition_order),
+                                   force_lpc_order=args.force_lpc_order)
+    streams = eng.make_pcm_streams((i * pcm_stride, nsamples, i * cap, cap, rate, channels, bps, bytes(infos[i % unique].md5))
+                                   for i in range(nfiles))
+    res = eng.encode_batch_device(d_pcm, pcm_stride * nfiles, d_enc, out_bytes, streams, opts, hip_stream=hip_stream)
+    bad = [i for i in range(nfiles) if res[i].status != 0]
+    assert not bad, f"{len(bad)} streams did not fit their capacity (first: {bad[:4]})"
+    if rank == 0:
+        import oracle
+        for i in sorted({0, nfiles // 2, nfiles - 1}):
+            f = d_enc[i * cap: i * cap + int(res[i].out_length)].cpu().numpy().tobytes()
+            md = flac_amd.parse_metadata(f)
+            osi = oracle.StreamInfo()
+            ctypes.memmove(ctypes.byref(osi), ctypes.byref(md.streaminfo), ctypes.sizeof(osi))
+            pcm, st = oracle.decode_stream(f[md.first_frame_offset:], osi)
+            assert hashlib.md5(pcm.tobytes()).hexdigest() == infos[i % unique].md5_signature, f"encode round trip, stream {i}"
+    kernel_ms = {k: 0.0 for k in ("stats_ms", "design_ms", "choose_ms", "layout_ms", "pack_ms", "crc_ms", "total_ms")}
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.encode_steps):
+        res = eng.encode_batch_device(d_pcm, pcm_stride * nfiles, d_enc, out_bytes, streams, opts, hip_stream=hip_stream)
+        t = eng.encode_timing()
+        for k in kernel_ms:
+            kernel_ms[k] += getattr(t, k) / args.encode_steps
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    flac_total = sum(int(r.out_length) for r in res)
+    pcm_total = nfiles * pcm_bytes_per_file
+    values = nfiles * nsamples * channels
+    alg = pcm_total + flac_total
+    dom = max(("stats_ms", "choose_ms", "pack_ms"), key=lambda k: kernel_ms[k])
+    a_s = kernel_ms[dom] / 1e3
+    return {"metric": "encoded PCM samples/sec (per GPU)", "value": values * args.encode_steps / elapsed, "unit": "samples/s",
+            "steps": args.encode_steps, "ms_per_step": elapsed / args.encode_steps * 1e3, "flac_GB": flac_total / 1e9,
+            "ratio": flac_total / pcm_total, "algorithmic_GB_per_s": alg * args.encode_steps / elapsed / 1e9,
+            "kernel_ms": kernel_ms,
+            "roofline": {"bound": "hbm", "kernel": "k_enc_" + dom[:-3], "achieved": alg / a_s / 1e9 if a_s > 0 else 0.0, "peak": 8000.0,
+                         "unit": "GB/s", "frac": alg / a_s / 1e9 / 8000.0 if a_s > 0 else 0.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kernel_ms[dom]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +113,7 @@ def main():
     ap.add_argument("--cpu-files", type=int, default=256, help="files of the workload timed on the host CPU (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU sample is decoded repeatedly for about this long")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
+    ap.add_argument("--encode-steps", type=int, default=2, help="timed steps of the encode leg (0 = skip it)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,6 +244,12 @@ def main():
     for k in kernel_ms:
         kernel_ms[k] /= max(1, args.steps)
 
+    # ---- encode leg: the PCM just decoded, encoded again on the device (reported beside the headline metric) ----
+    enc = None
+    if args.encode_steps > 0:
+        enc = encode_leg(args, dec, dev, rank, world, d_in, d_out, out_stride, nfiles, nsamples, channels, bps, rate,
+                         blocksize, pcm_bytes_per_file, infos, unique, hip_stream, threads)
+
     # ---- CPU baseline: the oracle (a scalar C port), timed on this host's cores on a sample ---
     cpu = None
     if rank == 0 and args.cpu_files > 0:
@@ -260,6 +326,7 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms["decode_ms"]},
             "cpu_baseline": cpu,
+            "encode": enc,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -130,7 +130,8 @@ class EncodeResult(ctypes.Structure):
 
 
 class EncodeTiming(ctypes.Structure):
-    _fields_ = [("analyze_ms", ctypes.c_float), ("layout_ms", ctypes.c_float), ("pack_ms", ctypes.c_float),
+    _fields_ = [("stats_ms", ctypes.c_float), ("design_ms", ctypes.c_float), ("choose_ms", ctypes.c_float),
+                ("layout_ms", ctypes.c_float), ("pack_ms", ctypes.c_float),
                 ("crc_ms", ctypes.c_float), ("md5_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("frames", ctypes.c_uint64), ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64)]
 

@@ -2,9 +2,11 @@
 // STREAMINFO block laid out as flacmeta.go:644-717 reads it).
 //
 // One encode call runs:
-//   k_enc_analyze  workgroup per (frame, candidate channel): wasted bits, constant test, fixed-predictor
-//                  error sums, windowed autocorrelation, Levinson-Durbin, coefficient quantisation,
-//                  residuals, Rice partition search -> a "plan" with the exact subframe size in bits
+//   k_enc_stats    workgroup per (frame, candidate channel): wasted bits, constant test, fixed-predictor
+//                  error sums, windowed autocorrelation
+//   k_enc_design   lane per candidate: Levinson-Durbin, order choice, coefficient quantisation
+//   k_enc_choose   workgroup per candidate: residuals, Rice partition search -> a "plan" with the exact
+//                  subframe size in bits
 //   k_enc_layout   workgroup per stream: stereo decision per frame, frame sizes, their prefix sum (= where
 //                  every frame and subframe goes), frame headers, STREAMINFO
 //   k_enc_pack     workgroup per (frame, channel): residuals again, code lengths, their prefix sum, bits
@@ -27,6 +29,16 @@ constexpr int kEncMaxBs = 16384;
 constexpr int kEncMaxPo = 8;
 constexpr int kPlanHeadBytes = 16;
 constexpr int kPlanCoefBytes = 64;   // 32 x int16
+
+// Samples of a block in LDS: kFront zeros in front (history of the first lane, whole runs), then the block.
+// One unused word follows every run of 16, so a lane's run starts 17 words after its neighbour's and the
+// lanes of a wave, each reading its own run and the ones before it, fall into different banks.
+constexpr int kFront = 48;
+__host__ __device__ constexpr uint32_t enc_lds_words(int NT) { return (uint32_t)((kFront + NT * kRun) / kRun * (kRun + 1) + 1); }
+__device__ inline uint32_t lds_pos(uint32_t j) { return j + (j >> 4); }            // j = kFront + sample index
+__device__ inline uint32_t lds_lane_base(uint32_t t) { return (uint32_t)(kFront + kFront / kRun) + t * (kRun + 1); }
+// word offset from lds_lane_base of the sample r places after the lane's first one (r may be negative)
+__host__ __device__ constexpr int lds_rel(int r) { return r + (r >= 0 ? r / kRun : -((-r + kRun - 1) / kRun)); }
 
 struct EncStreamDev {
     uint64_t in_off;          // bytes from d_pcm to sample 0
@@ -77,17 +89,66 @@ struct FrameRec {             // 64 bytes
 
 // ------------------------------------------------------------------ helpers ---
 
+// Lane exchanges inside a row of 16 lanes as DPP moves (vector ALU, no LDS traffic): partners at distance
+// 1 and 2 inside each quad, then the mirror images inside 8 and inside 16 lanes.  After the first two
+// steps a quad holds one value, after the third an 8-lane group does, so the mirrors pair the same groups
+// as partners at distance 4 and 8 would.
+#define FLACGPU_DPP_XOR1 0xB1         /* quad_perm [1,0,3,2] */
+#define FLACGPU_DPP_XOR2 0x4E         /* quad_perm [2,3,0,1] */
+#define FLACGPU_DPP_HALF_MIRROR 0x141
+#define FLACGPU_DPP_MIRROR 0x140
+template <int CTRL>
+__device__ inline uint32_t dpp_move(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ inline uint64_t dpp_move64(uint64_t v)
+{
+    return ((uint64_t)dpp_move<CTRL>((uint32_t)(v >> 32)) << 32) | dpp_move<CTRL>((uint32_t)v);
+}
+template <int CTRL>
+__device__ inline double dpp_move_f64(double v)
+{
+    return __hiloint2double((int)dpp_move<CTRL>((uint32_t)__double2hiint(v)), (int)dpp_move<CTRL>((uint32_t)__double2loint(v)));
+}
+// Reductions over a row of 16 lanes: every lane of the row ends with the row's value.
+__device__ inline uint32_t row_or(uint32_t v)
+{
+    v |= dpp_move<FLACGPU_DPP_XOR1>(v); v |= dpp_move<FLACGPU_DPP_XOR2>(v);
+    v |= dpp_move<FLACGPU_DPP_HALF_MIRROR>(v); v |= dpp_move<FLACGPU_DPP_MIRROR>(v);
+    return v;
+}
+__device__ inline uint32_t row_sum32(uint32_t v)
+{
+    v += dpp_move<FLACGPU_DPP_XOR1>(v); v += dpp_move<FLACGPU_DPP_XOR2>(v);
+    v += dpp_move<FLACGPU_DPP_HALF_MIRROR>(v); v += dpp_move<FLACGPU_DPP_MIRROR>(v);
+    return v;
+}
+__device__ inline uint64_t row_sum64(uint64_t v)
+{
+    v += dpp_move64<FLACGPU_DPP_XOR1>(v); v += dpp_move64<FLACGPU_DPP_XOR2>(v);
+    v += dpp_move64<FLACGPU_DPP_HALF_MIRROR>(v); v += dpp_move64<FLACGPU_DPP_MIRROR>(v);
+    return v;
+}
+// Butterfly sum over a row: partners at distance 1, 2, 4, 8; every lane ends with the same value.
+__device__ inline double row_butterfly(double v)
+{
+    v = v + dpp_move_f64<FLACGPU_DPP_XOR1>(v); v = v + dpp_move_f64<FLACGPU_DPP_XOR2>(v);
+    v = v + dpp_move_f64<FLACGPU_DPP_HALF_MIRROR>(v); v = v + dpp_move_f64<FLACGPU_DPP_MIRROR>(v);
+    return v;
+}
 __device__ inline uint32_t wave_or(uint32_t v)
 {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v |= (uint32_t)__shfl_xor((int)v, m);
-    return v;
+    v = row_or(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 __device__ inline uint32_t wave_sum32(uint32_t v)
 {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m);
-    return v;
+    v = row_sum32(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 __device__ inline uint32_t wave_min32(uint32_t v)
 {
@@ -103,16 +164,13 @@ __device__ inline uint32_t wave_max32(uint32_t v)
 }
 __device__ inline uint64_t wave_sum64(uint64_t v)
 {
+    v = row_sum64(v);
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    uint64_t r = 0;
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += (uint64_t)__shfl_xor((long long)v, m);
-    return v;
-}
-// Butterfly sum: every lane ends with the same value, formed in the same order.
-__device__ inline double wave_butterfly(double v)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m);
-    return v;
+    for (int l = 0; l < 64; l += 16)
+        r += ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, l);
+    return r;
 }
 
 // Exclusive prefix sum over the workgroup; s_w needs NT / 64 entries.
@@ -176,9 +234,12 @@ __device__ inline int32_t cand_sample(const uint8_t *src, uint32_t i, int C, int
     return load_le(src + ((size_t)i * C + cand) * B, B);
 }
 
-__device__ inline int find_enc_stream(const EncStreamDev *s, uint32_t n, uint32_t idx, int which)
+// Stream that owns plan unit (which = 0) or pack unit (which = 1) idx.  hints[k] is the owner of unit k << 10
+// (built on the host), so the search runs over the few streams between two hints.
+__device__ inline int find_enc_stream(const EncStreamDev *s, uint32_t n, const uint32_t *hints, uint32_t idx, int which)
 {
-    uint32_t lo = 0, hi = n;   // last stream whose begin <= idx
+    uint32_t lo = hints[idx >> 10], hi = hints[(idx >> 10) + 1] + 1;   // last stream in [lo, hi) whose begin <= idx
+    if (hi > n) hi = n;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         const uint32_t b = which == 0 ? s[mid].unit_begin : s[mid].pack_begin;
@@ -296,62 +357,290 @@ __device__ inline uint32_t lpc_residual(const int32_t (&w)[M + kRun], const int3
 }
 
 // ----------------------------------------------------------------- analysis ---
+//
+// Three kernels per encode call:
+//   k_enc_stats   workgroup per candidate channel: wasted bits, constant test, fixed-predictor error
+//                 sums, windowed autocorrelation                          -> CandStats
+//   k_enc_design  LANE per candidate channel: Levinson-Durbin, order choice, coefficient quantisation
+//                 (serial arithmetic, so one lane each and registers only) -> CandStats
+//   k_enc_choose  workgroup per candidate channel: residuals of the best fixed predictor and of the LPC
+//                 predictor, Rice partition search for both, cheapest subframe -> plan
 
-template <int NT>
-struct AnalyzeShared {
-    uint64_t psum[2][NT];            // per lane: sum of folded residuals (0 fixed, 1 lpc)
-    uint64_t heap[2][512];           // partition sums, node n has children 2n and 2n + 1
-    uint64_t e[5];                   // fixed-predictor error sums
-    double   wsum[NT / 64][17];      // per wave autocorrelation sums of one lag group
-    double   ac[33];
-    double   tmp[32], best[32];
-    uint32_t lvl_total[2][kEncMaxPo + 1];
-    uint32_t need5[2];
-    uint32_t exact[2];
-    uint32_t ored, neq, lpc_bad;
-    int32_t  q[32];
-    int32_t  fo, lpc_ok, ord, prec, shift, wide;
-    int32_t  po[2], method[2], L[2], lo[2];
-    uint8_t  kb[2][512];
+struct CandStats {            // followed by (M + 1) doubles: autocorrelation lags 0..M
+    uint32_t constant;        // all samples equal: the plan is already written
+    uint32_t wasted;
+    uint32_t fo;              // best fixed order
+    uint32_t lpc_ok;
+    int32_t  ord, prec, shift, wide;
+    int16_t  q[32];
+};
+constexpr int kStatsHeadBytes = 96;
+__host__ __device__ inline uint32_t stats_stride(int M) { return (uint32_t)(kStatsHeadBytes + (M + 1) * 8); }
+
+// Candidate channel a workgroup (or lane) works on.
+struct UnitInfo {
+    const EncStreamDev *st;
+    uint32_t f, cand, bs;
+    int C, B, cbps;
+    bool stereo, last;
+    const uint8_t *src;
 };
 
-// Levinson-Durbin, order choice and coefficient quantisation, run by one thread.
-template <int NT>
-__device__ __noinline__ void design_predictor(AnalyzeShared<NT> &S, const EncOptsDev &o, uint32_t bs, int sb, int stream_bps,
-                                              uint32_t maxo)
+__device__ inline UnitInfo unit_info(const uint8_t *pcm, const EncStreamDev *streams, uint32_t n_streams, const uint32_t *hints,
+                                     const EncOptsDev &o, uint32_t unit)
 {
-    S.lpc_ok = 0; S.ord = 0;
-    if (!(S.ac[0] > 0)) return;
+    UnitInfo u;
+    const int si = find_enc_stream(streams, n_streams, hints, unit, 0);
+    u.st = &streams[si];
+    const uint32_t ncand = u.st->ncand, rel = unit - u.st->unit_begin;
+    u.f = rel / ncand;
+    u.cand = rel - u.f * ncand;
+    u.last = u.f + 1 == u.st->n_frames;
+    u.bs = u.last ? u.st->tail_bs : o.blocksize;
+    u.C = u.st->channels; u.B = u.st->bytes_ps;
+    u.stereo = u.C == 2;
+    u.cbps = u.st->bps + (u.stereo && u.cand == 3 ? 1 : 0);
+    u.src = pcm + u.st->in_off + (uint64_t)u.f * o.blocksize * (uint32_t)(u.C * u.B);
+    return u;
+}
+
+template <int NT>
+struct StatsShared {
+    uint64_t e[5];                   // fixed-predictor error sums
+    double   rsum[NT / 16][17];      // per row of 16 lanes: autocorrelation sums of one lag group
+    uint32_t ored, neq;
+};
+
+template <int M, int NT>
+__global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
+                                                  uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
+                                                  const float *__restrict__ windows, uint8_t *__restrict__ stats,
+                                                  uint8_t *__restrict__ plans)
+{
+    extern __shared__ __align__(16) int32_t xs[];   // enc_lds_words(NT): see lds_pos
+    __shared__ StatsShared<NT> S;
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x);
+    if (unit >= o.total_units) return;
+    const UnitInfo u = unit_info(pcm, streams, n_streams, hints, o, unit);
+    const uint32_t bs = u.bs;
+    const float *win = windows + (u.last ? u.st->win_off_tail : u.st->win_off);
+    CandStats *cs = reinterpret_cast<CandStats *>(stats + (uint64_t)unit * stats_stride(M));
+    double *cs_ac = reinterpret_cast<double *>(stats + (uint64_t)unit * stats_stride(M) + kStatsHeadBytes);
+
+    if (t == 0) {
+        S.ored = 0; S.neq = 0;
+        for (int k = 0; k < 5; ++k) S.e[k] = 0;
+    }
+    // ---- load, wasted bits, constant test
+    int32_t v[kRun];
+    uint32_t ored = 0, neq = 0;
+    const int32_t first = cand_sample(u.src, 0, u.C, u.B, (int)u.cand, u.stereo);
+    // every load is issued (index clamped into the block) so that the 16 of them overlap
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const uint32_t i = t + (uint32_t)j * NT;
+        v[j] = cand_sample(u.src, i < bs ? i : bs - 1, u.C, u.B, (int)u.cand, u.stereo);
+    }
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const uint32_t i = t + (uint32_t)j * NT;
+        if (i >= bs) v[j] = 0;
+        ored |= (uint32_t)v[j];
+        neq |= i < bs ? (uint32_t)(v[j] ^ first) : 0u;
+    }
+    __syncthreads();
+    ored = wave_or(ored); neq = wave_or(neq);
+    if (lane == 0) { if (ored) atomicOr(&S.ored, ored); if (neq) atomicOr(&S.neq, neq); }
+    __syncthreads();
+    int wasted = S.ored ? __ffs((int)S.ored) - 1 : 0;
+    if (wasted >= u.cbps) wasted = u.cbps - 1;
+    const int sb = u.cbps - wasted;
+    if (S.neq == 0) {
+        if (t == 0) {
+            PlanHead h = {};
+            h.bits = 8 + (uint32_t)wasted + (uint32_t)sb; h.type = 0; h.wasted = (uint8_t)wasted; h.sb = (uint8_t)sb;
+            *reinterpret_cast<PlanHead *>(plans + (uint64_t)unit * o.plan_stride) = h;
+            cs->constant = 1; cs->wasted = (uint32_t)wasted; cs->fo = 0; cs->lpc_ok = 0;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) xs[lds_pos(kFront + t + (uint32_t)j * NT)] = v[j] >> wasted;
+    if (t < lds_lane_base(0)) xs[t] = 0;
+    __syncthreads();
+
+    const uint32_t i0 = t * kRun, lbase = lds_lane_base(t);
+    int32_t mine[kRun];
+    // ---- fixed predictors: sums of absolute errors of orders 0..4 over samples 4 .. bs-1
+    {
+        int32_t w[4 + kRun];
+#pragma unroll
+        for (int m = 0; m < 4 + kRun; ++m) w[m] = xs[lbase + lds_rel(m - 4)];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) mine[j] = w[4 + j];
+        // 8 errors of at most 2^28 fit 32 bits; the two halves of the run are widened and added
+        uint64_t e64[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t e32[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int jj = 0; jj < kRun / 2; ++jj) {
+                const int j = half * (kRun / 2) + jj;
+                const uint32_t i = i0 + j;
+                if (i >= 4 && i < bs) {
+                    const int32_t a = w[4 + j], b = w[3 + j], c = w[2 + j], d = w[1 + j], e = w[j];
+                    const int32_t d1 = a - b, d2 = a - 2 * b + c, d3 = a - 3 * b + 3 * c - d, d4 = a - 4 * b + 6 * c - 4 * d + e;
+                    e32[0] += (uint32_t)(a < 0 ? -a : a); e32[1] += (uint32_t)(d1 < 0 ? -d1 : d1); e32[2] += (uint32_t)(d2 < 0 ? -d2 : d2);
+                    e32[3] += (uint32_t)(d3 < 0 ? -d3 : d3); e32[4] += (uint32_t)(d4 < 0 ? -d4 : d4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) e64[k] += e32[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint64_t rs = row_sum64(e64[k]);
+            if ((lane & 15) == 0 && rs) atomicAdd((unsigned long long *)&S.e[k], (unsigned long long)rs);
+        }
+    }
+    // ---- windowed autocorrelation, lags 0..maxo
+    uint32_t maxo = o.force_lpc_order ? o.force_lpc_order : o.max_lpc_order;
+    if (maxo > (uint32_t)M) maxo = M;
+    const bool try_lpc = maxo > 0 && bs > maxo;
+    if (try_lpc) {
+        // the samples in LDS are replaced by their windowed single-precision values
+        double own[kRun];
+        {
+            float wv[kRun];
+#pragma unroll
+            for (int q = 0; q < kRun / 4; ++q) {
+                const uint32_t i = i0 + 4 * q;
+                const float4 f4 = *reinterpret_cast<const float4 *>(win + (i < bs ? i : 0));   // tables are padded to 4
+                wv[4 * q] = f4.x; wv[4 * q + 1] = f4.y; wv[4 * q + 2] = f4.z; wv[4 * q + 3] = f4.w;
+            }
+            __syncthreads();   // every lane has read its integer samples
+            float *xf = reinterpret_cast<float *>(xs);
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                const float x = i0 + j < bs ? (float)mine[j] * wv[j] : 0.0f;
+                xf[lbase + j] = x;
+                own[j] = (double)x;
+            }
+            __syncthreads();
+        }
+        const float *xf = reinterpret_cast<const float *>(xs);
+        constexpr int LG = M <= 12 ? 13 : 17;
+#pragma unroll
+        for (int base = 0; base <= M; base += LG) {
+            if (base > (int)maxo) break;
+            double acc[LG];
+#pragma unroll
+            for (int l = 0; l < LG; ++l) acc[l] = 0.0;
+            // window element m is sample i0 - (base + LG - 1) + m; it meets own[j] at lag base + LG - 1 + j - m
+#pragma unroll
+            for (int m = 0; m < LG - 1 + kRun; ++m) {
+                const double d = (double)xf[lbase + lds_rel(m - (base + LG - 1))];   // zero padding below sample 0
+#pragma unroll
+                for (int j = 0; j < kRun; ++j) {
+                    const int l = LG - 1 + j - m;   // lag within the group
+                    if (l >= 0 && l < LG) acc[l] = __fma_rn(own[j], d, acc[l]);
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < LG; ++l) {
+                const double rs = row_butterfly(acc[l]);
+                if ((lane & 15) == 0) S.rsum[t >> 4][l] = rs;
+            }
+            __syncthreads();
+            // the butterfly goes on over the four rows of a wave, then the waves are added in ascending order
+            if (t < (uint32_t)LG && base + t <= maxo) {
+                double total = 0.0;
+                for (int w = 0; w < NT / 64; ++w) {
+                    const double ws = (S.rsum[4 * w][t] + S.rsum[4 * w + 1][t]) + (S.rsum[4 * w + 2][t] + S.rsum[4 * w + 3][t]);
+                    total = w ? total + ws : ws;
+                }
+                cs_ac[base + t] = total;
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+    if (t == 0) {
+        int fo = 0;
+        for (int k = 1; k <= 4; ++k) if (S.e[k] < S.e[fo]) fo = k;
+        if ((uint32_t)fo > bs) fo = (int)bs;
+        cs->constant = 0; cs->wasted = (uint32_t)wasted; cs->fo = (uint32_t)fo; cs->lpc_ok = 0;
+    }
+}
+
+// Levinson-Durbin, order choice and coefficient quantisation: one lane per candidate channel, every array
+// in registers (all loops unrolled, indices known at compile time).
+template <int M>
+__global__ __launch_bounds__(64) void k_enc_design(const EncStreamDev *__restrict__ streams, uint32_t n_streams,
+                                                   const uint32_t *__restrict__ hints, EncOptsDev o, uint8_t *__restrict__ stats)
+{
+    const uint32_t unit = blockIdx.x * 64 + threadIdx.x;
+    if (unit >= o.total_units) return;
+    CandStats *cs = reinterpret_cast<CandStats *>(stats + (uint64_t)unit * stats_stride(M));
+    if (cs->constant) return;
+    const UnitInfo u = unit_info(nullptr, streams, n_streams, hints, o, unit);
+    const uint32_t bs = u.bs;
+    uint32_t maxo = o.force_lpc_order ? o.force_lpc_order : o.max_lpc_order;
+    if (maxo > (uint32_t)M) maxo = M;
+    if (!(maxo > 0 && bs > maxo)) return;
+    const double *cs_ac = reinterpret_cast<const double *>(stats + (uint64_t)unit * stats_stride(M) + kStatsHeadBytes);
+    double ac[M + 1];
+#pragma unroll
+    for (int l = 0; l <= M; ++l) ac[l] = (uint32_t)l <= maxo ? cs_ac[l] : 0.0;
+    if (!(ac[0] > 0)) return;
+    const int sb = u.cbps - (int)cs->wasted, stream_bps = u.st->bps;
     int prec0 = o.qlp_precision ? (int)o.qlp_precision : default_precision(stream_bps, bs);
     prec0 = prec0 > 15 ? 15 : prec0 < 5 ? 5 : prec0;
-    double err = S.ac[0], bestb = 0;
+    double err = ac[0], bestb = 0;
     const double scale = 0x1.0a6a4c7c29f9ap+0 / (double)bs;   // 0.5 / ln(2)^2 / bs
+    double tmp[M], best[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) { tmp[j] = 0.0; best[j] = 0.0; }
     int ord = 0;
-    for (uint32_t i = 0; i < maxo; ++i) {
-        double r = -S.ac[i + 1];
-        for (uint32_t j = 0; j < i; ++j) r -= S.tmp[j] * S.ac[i - j];
-        if (err <= 0) break;
-        r /= err;
-        S.tmp[i] = r;
-        for (uint32_t j = 0; j < i / 2; ++j) {
-            const double t = S.tmp[j];
-            S.tmp[j] += r * S.tmp[i - 1 - j];
-            S.tmp[i - 1 - j] += r * t;
+    bool alive = true;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        if ((uint32_t)i < maxo && alive) {
+            double r = -ac[i + 1];
+#pragma unroll
+            for (int j = 0; j < i; ++j) r -= tmp[j] * ac[i - j];
+            if (err <= 0) alive = false;
+            else {
+                r /= err;
+                tmp[i] = r;
+#pragma unroll
+                for (int j = 0; j < i / 2; ++j) {
+                    const double tj = tmp[j];
+                    tmp[j] += r * tmp[i - 1 - j];
+                    tmp[i - 1 - j] += r * tj;
+                }
+                if (i & 1) tmp[i / 2] += tmp[i / 2] * r;
+                err *= (1.0 - r * r);
+                const uint32_t k = (uint32_t)i + 1;
+                bool take;
+                if (o.force_lpc_order) take = (k == o.force_lpc_order);
+                else {
+                    const double vv = err * scale;
+                    double bpr = vv > 0 ? 0.5 * est_log2(vv) : 0.0;
+                    if (bpr < 0) bpr = 0;
+                    const double tot = bpr * (double)(bs - k) + (double)k * (double)(sb + prec0);
+                    take = (ord == 0 || tot < bestb);
+                    if (take) bestb = tot;
+                }
+                if (take) {
+                    ord = (int)k;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) best[j] = -tmp[j];
+                }
+            }
         }
-        if (i & 1) S.tmp[i / 2] += S.tmp[i / 2] * r;
-        err *= (1.0 - r * r);
-        const uint32_t k = i + 1;
-        bool take;
-        if (o.force_lpc_order) take = (k == o.force_lpc_order);
-        else {
-            const double v = err * scale;
-            double bpr = v > 0 ? 0.5 * est_log2(v) : 0.0;
-            if (bpr < 0) bpr = 0;
-            const double tot = bpr * (double)(bs - k) + (double)k * (double)(sb + prec0);
-            take = (ord == 0 || tot < bestb);
-            if (take) bestb = tot;
-        }
-        if (take) { ord = (int)k; for (uint32_t j = 0; j < k; ++j) S.best[j] = -S.tmp[j]; }
     }
     if (!ord) return;
     int prec = prec0;
@@ -360,7 +649,8 @@ __device__ __noinline__ void design_predictor(AnalyzeShared<NT> &S, const EncOpt
         if (prec > cap) prec = cap;
     }
     double cmax = 0;
-    for (int j = 0; j < ord; ++j) { const double a = __builtin_fabs(S.best[j]); if (a > cmax) cmax = a; }
+#pragma unroll
+    for (int j = 0; j < M; ++j) { const double a = __builtin_fabs(best[j]); if (j < ord && a > cmax) cmax = a; }
     if (!(cmax > 0)) return;
     const uint64_t cb = (uint64_t)__double_as_longlong(cmax);
     const int ex = (int)((cb >> 52) & 0x7FF) - 1022;
@@ -370,245 +660,196 @@ __device__ __noinline__ void design_predictor(AnalyzeShared<NT> &S, const EncOpt
     const double mul = shift >= 0 ? (double)(1 << shift) : 1.0 / (double)(1 << -shift);
     if (shift < 0) shift = 0;
     double carry = 0;
-    for (int j = 0; j < 32; ++j) S.q[j] = 0;
-    for (int j = 0; j < ord; ++j) {
-        carry += S.best[j] * mul;
-        int v = carry >= 0 ? (int)(carry + 0.5) : -(int)(0.5 - carry);
-        v = v > qmax ? qmax : v < qmin ? qmin : v;
-        carry -= (double)v;
-        S.q[j] = v;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        int qv = 0;
+        if (j < M && j < ord) {
+            carry += best[j < M ? j : 0] * mul;
+            qv = carry >= 0 ? (int)(carry + 0.5) : -(int)(0.5 - carry);
+            qv = qv > qmax ? qmax : qv < qmin ? qmin : qv;
+            carry -= (double)qv;
+        }
+        cs->q[j] = (int16_t)qv;
     }
-    S.ord = ord; S.prec = prec; S.shift = shift;
-    S.wide = (sb + prec + ilog2_32((uint32_t)ord)) > 32;
-    S.lpc_ok = 1;
+    cs->ord = ord; cs->prec = prec; cs->shift = shift;
+    cs->wide = (sb + prec + ilog2_32((uint32_t)ord)) > 32;
+    cs->lpc_ok = 1;
 }
 
-// Partition search of one predictor's residual: fills S.po / S.method / S.kb / S.exact for slot `which`.
-// Called by the whole workgroup.  u: the lane's folded residuals, order: warm-up samples.
 template <int NT>
-__device__ inline void rice_search(AnalyzeShared<NT> &S, const EncOptsDev &o, int which, uint32_t bs, uint32_t order,
-                                   const uint32_t (&u)[kRun])
+struct ChooseShared {
+    uint64_t psum[2][NT];            // per lane: sum of folded residuals (0 fixed, 1 lpc)
+    uint64_t heap[2][512];           // partition sums, node n has children 2n and 2n + 1
+    uint32_t lvl_total[2][kEncMaxPo + 1];
+    uint32_t need5[2];
+    uint32_t exact[2];
+    uint32_t lpc_bad;
+    int32_t  q[32];
+    int32_t  po[2], method[2];
+    uint8_t  kb[2][512];
+};
+
+// Partition search of the residuals of both predictors at once (slot 0 fixed, slot 1 lpc when use1): fills
+// S.po / S.method / S.kb / S.exact.  Called by the whole workgroup.  uf / ul: the lane's folded residuals.
+// Sums of the partitions of every order are kept as a heap (node n has children 2n and 2n + 1); a pass
+// fills three levels from the level below them, so an order-6 search takes two passes.
+template <int NT>
+__device__ inline void rice_search_both(ChooseShared<NT> &S, const EncOptsDev &o, uint32_t bs, uint32_t order0, uint32_t order1,
+                                        bool use1, const uint32_t (&uf)[kRun], const uint32_t (&ul)[kRun])
 {
     const uint32_t t = threadIdx.x, lane = t & 63;
     const uint32_t lanes = (bs + kRun - 1) / kRun;
-    const int L = max_partition_order(bs, order, o.max_po);
-    const int lo = (int)o.min_po > L ? L : (int)o.min_po;
-    const uint32_t P = 1u << L, tpp = L ? (bs >> L) / kRun : lanes;
-    uint64_t *heap = S.heap[which];
-    if (L == 0) {
-        const uint64_t ws = wave_sum64(t < lanes ? S.psum[which][t] : 0);
-        if (lane == 0 && ws) atomicAdd((unsigned long long *)&heap[1], (unsigned long long)ws);
-    } else if (t < P) {
-        uint64_t s = 0;
-        for (uint32_t q = 0; q < tpp; ++q) s += S.psum[which][t * tpp + q];
-        heap[P + t] = s;
+    const uint32_t nsearch = use1 ? 2 : 1;
+    const uint32_t ord[2] = {order0, order1};
+    int L[2], lo[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        L[w] = max_partition_order(bs, ord[w], o.max_po);
+        lo[w] = (int)o.min_po > L[w] ? L[w] : (int)o.min_po;
+    }
+    const int Lmax = (use1 && L[1] > L[0]) ? L[1] : L[0];
+    // leaves: the finest partitions, whole runs of lanes
+    for (uint32_t w = 0; w < nsearch; ++w) {
+        if (L[w] == 0) {
+            const uint64_t ws = wave_sum64(t < lanes ? S.psum[w][t] : 0);
+            if (lane == 0 && ws) atomicAdd((unsigned long long *)&S.heap[w][1], (unsigned long long)ws);
+        }
+    }
+    for (uint32_t idx = t; idx < (nsearch << Lmax); idx += NT) {
+        const uint32_t w = idx >> Lmax, p = idx & ((1u << Lmax) - 1);
+        if (L[w] > 0 && p < (1u << L[w])) {
+            const uint32_t tpp = (bs >> L[w]) / kRun;
+            uint64_t sum = 0;
+            for (uint32_t q = 0; q < tpp; ++q) sum += S.psum[w][p * tpp + q];
+            S.heap[w][(1u << L[w]) + p] = sum;
+        }
     }
     __syncthreads();
-    for (int l = L - 1; l >= lo; --l) {
-        if (t < (1u << l)) { const uint32_t n = (1u << l) + t; heap[n] = heap[2 * n] + heap[2 * n + 1]; }
+    // coarser levels, three per pass: nodes [2^(l-3), 2^l) from their descendants at level l, where l starts
+    // at each search's own finest level
+    for (int step = 0; 3 * step < Lmax; ++step) {
+        for (uint32_t idx = t; idx < (nsearch << Lmax); idx += NT) {
+            const uint32_t w = idx >> Lmax, n = idx & ((1u << Lmax) - 1);
+            const int l = L[w] - 3 * step;
+            if (l > 0 && n < (1u << l) && n >= (1u << (l >= 3 ? l - 3 : 0))) {
+                const int k = ilog2_32(n);
+                if (k >= lo[w]) {
+                    const uint32_t span = 1u << (l - k), first = ((n - (1u << k)) << (l - k)) + (1u << l);
+                    uint64_t sum = 0;
+                    for (uint32_t q = 0; q < span; ++q) sum += S.heap[w][first + q];
+                    S.heap[w][n] = sum;
+                }
+            }
+        }
         __syncthreads();
     }
-    for (uint32_t n = (1u << lo) + t; n < (2u << L); n += NT) {
-        const int l = ilog2_32(n);
-        const uint32_t p = n - (1u << l);
-        const uint32_t cnt = (bs >> l) - (p == 0 ? order : 0);
-        uint32_t est;
-        const uint32_t k = rice_param(heap[n], cnt, est);
-        S.kb[which][n] = (uint8_t)k;
-        atomicAdd(&S.lvl_total[which][l], est);
-        if (k > 14) atomicOr(&S.need5[which], 1u << l);
+    // every partition of every order: parameter and estimated size
+    for (uint32_t idx = t; idx < (nsearch << (Lmax + 1)); idx += NT) {
+        const uint32_t w = idx >> (Lmax + 1), n = idx & ((2u << Lmax) - 1);
+        if (n >= (1u << lo[w]) && n < (2u << L[w])) {
+            const int l = ilog2_32(n);
+            const uint32_t p = n - (1u << l);
+            const uint32_t cnt = (bs >> l) - (p == 0 ? ord[w] : 0);
+            uint32_t est;
+            const uint32_t k = rice_param(S.heap[w][n], cnt, est);
+            S.kb[w][n] = (uint8_t)k;
+            atomicAdd(&S.lvl_total[w][l], est);
+            if (k > 14) atomicOr(&S.need5[w], 1u << l);
+        }
     }
     __syncthreads();
-    if (t == 0) {
+    if ((t == 0 || t == 64) && (t >> 6) < nsearch) {
+        const uint32_t w = t >> 6;
         uint32_t best = 0xFFFFFFFFu;
-        int bl = L, bm = 0;
-        for (int l = L; l >= lo; --l) {
-            const int n5 = (S.need5[which] >> l) & 1;
-            const uint32_t total = S.lvl_total[which][l] + ((n5 ? 5u : 4u) << l);
+        int bl = L[w], bm = 0;
+        for (int l = L[w]; l >= lo[w]; --l) {
+            const int n5 = (S.need5[w] >> l) & 1;
+            const uint32_t total = S.lvl_total[w][l] + ((n5 ? 5u : 4u) << l);
             if (total < best) { best = total; bl = l; bm = n5; }
         }
-        S.po[which] = bl; S.method[which] = bm;
+        S.po[w] = bl; S.method[w] = bm;
     }
     __syncthreads();
-    const int po = S.po[which];
-    const uint32_t part = po ? (t * kRun) / (bs >> po) : 0;
-    uint32_t exact = 0;
+    // exact size of the chosen partitioning
+    uint32_t exact0 = 0, exact1 = 0;
     if (t < lanes) {
-        const uint32_t k = S.kb[which][(1u << po) + (part < (1u << po) ? part : 0)];
+        const int po0 = S.po[0], po1 = S.po[1];
+        const uint32_t part0 = po0 ? (t * kRun) / (bs >> po0) : 0, part1 = po1 ? (t * kRun) / (bs >> po1) : 0;
+        const uint32_t k0 = S.kb[0][(1u << po0) + part0], k1 = use1 ? S.kb[1][(1u << po1) + part1] : 0;
 #pragma unroll
         for (int j = 0; j < kRun; ++j) {
             const uint32_t i = t * kRun + j;
-            if (i >= order && i < bs) exact += (u[j] >> k) + k + 1;
+            if (i >= order0 && i < bs) exact0 += (uf[j] >> k0) + k0 + 1;
+            if (use1 && i >= order1 && i < bs) exact1 += (ul[j] >> k1) + k1 + 1;
         }
     }
-    exact = wave_sum32(exact);
-    if (lane == 0 && exact) atomicAdd(&S.exact[which], exact);
+    exact0 = row_sum32(exact0);
+    exact1 = row_sum32(exact1);
+    if ((lane & 15) == 0) {
+        if (exact0) atomicAdd(&S.exact[0], exact0);
+        if (exact1) atomicAdd(&S.exact[1], exact1);
+    }
 }
 
 template <int M, int NT>
-__global__ __launch_bounds__(NT) void k_enc_analyze(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
-                                                    uint32_t n_streams, EncOptsDev o, const float *__restrict__ windows,
-                                                    uint8_t *__restrict__ plans)
+__global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
+                                                   uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
+                                                   const uint8_t *__restrict__ stats, uint8_t *__restrict__ plans)
 {
-    extern __shared__ __align__(16) int32_t xs[];   // M zeros, then NT * kRun samples
-    __shared__ AnalyzeShared<NT> S;
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    extern __shared__ __align__(16) int32_t xs[];   // enc_lds_words(NT): see lds_pos
+    __shared__ ChooseShared<NT> S;
+    const uint32_t t = threadIdx.x;
     const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x);
     if (unit >= o.total_units) return;
-    const int si = find_enc_stream(streams, n_streams, unit, 0);
-    const EncStreamDev &st = streams[si];
-    const uint32_t ncand = st.ncand, rel = unit - st.unit_begin;
-    const uint32_t f = rel / ncand, cand = rel - f * ncand;
-    const bool last = f + 1 == st.n_frames;
-    const uint32_t bs = last ? st.tail_bs : o.blocksize;
-    const float *win = windows + (last ? st.win_off_tail : st.win_off);
-    const int C = st.channels, B = st.bytes_ps, stream_bps = st.bps;
-    const bool stereo4 = C == 2;
-    const int cbps = stream_bps + (stereo4 && cand == 3 ? 1 : 0);
-    const uint8_t *src = pcm + st.in_off + (uint64_t)f * o.blocksize * (uint32_t)(C * B);
+    const CandStats *cs = reinterpret_cast<const CandStats *>(stats + (uint64_t)unit * stats_stride(M));
+    if (cs->constant) return;
+    const UnitInfo u = unit_info(pcm, streams, n_streams, hints, o, unit);
+    const uint32_t bs = u.bs;
     uint8_t *plan = plans + (uint64_t)unit * o.plan_stride;
-    const uint32_t lanes = (bs + kRun - 1) / kRun;
+    const int wasted = (int)cs->wasted, sb = u.cbps - wasted;
+    const uint32_t hdr = 8 + (uint32_t)wasted;
+    const int fo = (int)cs->fo, lpc_ok = (int)cs->lpc_ok, ord = lpc_ok ? cs->ord : 0;
+    const int prec = cs->prec, shift = cs->shift, wide = cs->wide;
 
     if (t == 0) {
-        S.ored = 0; S.neq = 0; S.lpc_bad = 0; S.lpc_ok = 0; S.ord = 0;
-        for (int k = 0; k < 5; ++k) S.e[k] = 0;
+        S.lpc_bad = 0;
         for (int w = 0; w < 2; ++w) {
-            S.need5[w] = 0; S.exact[w] = 0; S.heap[w][1] = 0;
+            S.need5[w] = 0; S.exact[w] = 0; S.heap[w][1] = 0; S.po[w] = 0; S.method[w] = 0;
             for (int l = 0; l <= kEncMaxPo; ++l) S.lvl_total[w][l] = 0;
         }
     }
-    // ---- load, wasted bits, constant test
-    int32_t v[kRun];
-    uint32_t ored = 0, neq = 0;
-    const int32_t first = cand_sample(src, 0, C, B, (int)cand, stereo4);
-#pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-        const uint32_t i = t + (uint32_t)j * NT;
-        v[j] = 0;
-        if (i < bs) {
-            v[j] = cand_sample(src, i, C, B, (int)cand, stereo4);
-            ored |= (uint32_t)v[j];
-            neq |= (uint32_t)(v[j] ^ first);
-        }
-    }
-    __syncthreads();
-    ored = wave_or(ored); neq = wave_or(neq);
-    if (lane == 0) { if (ored) atomicOr(&S.ored, ored); if (neq) atomicOr(&S.neq, neq); }
-    __syncthreads();
-    int wasted = S.ored ? __ffs((int)S.ored) - 1 : 0;
-    if (wasted >= cbps) wasted = cbps - 1;
-    const int sb = cbps - wasted;
-    const uint32_t hdr = 8 + (uint32_t)wasted;
-    if (S.neq == 0) {
-        if (t == 0) {
-            PlanHead h = {};
-            h.bits = hdr + (uint32_t)sb; h.type = 0; h.wasted = (uint8_t)wasted; h.sb = (uint8_t)sb;
-            *reinterpret_cast<PlanHead *>(plan) = h;
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < kRun; ++j) xs[M + t + (uint32_t)j * NT] = v[j] >> wasted;
-    if (t < (uint32_t)M) xs[t] = 0;
-    __syncthreads();
-
-    const uint32_t i0 = t * kRun;
-    // ---- fixed predictors: sums of absolute errors of orders 0..4 over samples 4 .. bs-1
+    if (t < 32) S.q[t] = lpc_ok ? (int32_t)cs->q[t] : 0;
     {
-        int32_t w[4 + kRun];
-#pragma unroll
-        for (int m = 0; m < 4 + kRun; ++m) w[m] = xs[M + i0 - 4 + m];
-        uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+        int32_t v[kRun];
 #pragma unroll
         for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = i0 + j;
-            if (i >= 4 && i < bs) {
-                const int32_t a = w[4 + j], b = w[3 + j], c = w[2 + j], d = w[1 + j], e = w[j];
-                const int32_t d1 = a - b, d2 = a - 2 * b + c, d3 = a - 3 * b + 3 * c - d, d4 = a - 4 * b + 6 * c - 4 * d + e;
-                e0 += (uint32_t)(a < 0 ? -a : a); e1 += (uint32_t)(d1 < 0 ? -d1 : d1); e2 += (uint32_t)(d2 < 0 ? -d2 : d2);
-                e3 += (uint32_t)(d3 < 0 ? -d3 : d3); e4 += (uint32_t)(d4 < 0 ? -d4 : d4);
-            }
+            const uint32_t i = t + (uint32_t)j * NT;
+            v[j] = cand_sample(u.src, i < bs ? i : bs - 1, u.C, u.B, (int)u.cand, u.stereo);
         }
-        e0 = wave_sum64(e0); e1 = wave_sum64(e1); e2 = wave_sum64(e2); e3 = wave_sum64(e3); e4 = wave_sum64(e4);
-        if (lane == 0) {
-            atomicAdd((unsigned long long *)&S.e[0], (unsigned long long)e0);
-            atomicAdd((unsigned long long *)&S.e[1], (unsigned long long)e1);
-            atomicAdd((unsigned long long *)&S.e[2], (unsigned long long)e2);
-            atomicAdd((unsigned long long *)&S.e[3], (unsigned long long)e3);
-            atomicAdd((unsigned long long *)&S.e[4], (unsigned long long)e4);
-        }
-    }
-    // ---- windowed autocorrelation, lags 0..maxo
-    uint32_t maxo = o.force_lpc_order ? o.force_lpc_order : o.max_lpc_order;
-    if (maxo > (uint32_t)M) maxo = M;
-    const bool try_lpc = maxo > 0 && bs > maxo;
-    if (try_lpc) {
-        double own[kRun];
 #pragma unroll
         for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = i0 + j;
-            const float wv = i < bs ? win[i] : 0.0f;
-            own[j] = (double)((float)xs[M + i] * wv);
+            const uint32_t i = t + (uint32_t)j * NT;
+            xs[lds_pos(kFront + i)] = i < bs ? v[j] >> wasted : 0;
         }
-        constexpr int LG = M <= 12 ? 13 : 17;
-#pragma unroll 1
-        for (int base = 0; base <= (int)maxo; base += LG) {
-            double acc[LG];
-#pragma unroll
-            for (int l = 0; l < LG; ++l) acc[l] = 0.0;
-            // window element m is sample i0 - (base + LG - 1) + m; it meets own[j] at lag base + LG - 1 + j - m
-#pragma unroll
-            for (int m = 0; m < LG - 1 + kRun; ++m) {
-                const int32_t idx = (int32_t)i0 - (base + LG - 1) + m;
-                double d = 0.0;
-                if (idx >= 0 && (uint32_t)idx < bs) d = (double)((float)xs[M + idx] * win[idx]);
-#pragma unroll
-                for (int j = 0; j < kRun; ++j) {
-                    const int l = LG - 1 + j - m;   // lag within the group
-                    if (l >= 0 && l < LG) acc[l] = __fma_rn(own[j], d, acc[l]);
-                }
-            }
-#pragma unroll
-            for (int l = 0; l < LG; ++l) {
-                const double wsum = wave_butterfly(acc[l]);
-                if (lane == 0) S.wsum[wave][l] = wsum;
-            }
-            __syncthreads();
-            if (t < (uint32_t)LG && base + t <= maxo) {
-                double total = S.wsum[0][t];
-                for (int w = 1; w < NT / 64; ++w) total = total + S.wsum[w][t];
-                S.ac[base + t] = total;
-            }
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
     }
-    // ---- predictor design by one thread
-    if (t == 0) {
-        int fo = 0;
-        for (int k = 1; k <= 4; ++k) if (S.e[k] < S.e[fo]) fo = k;
-        if ((uint32_t)fo > bs) fo = (int)bs;
-        S.fo = fo;
-        if (try_lpc) design_predictor<NT>(S, o, bs, sb, stream_bps, maxo);
-    }
+    if (t < lds_lane_base(0)) xs[t] = 0;
     __syncthreads();
 
     // ---- residuals of both predictors
-    const int fo = S.fo, lpc_ok = S.lpc_ok, ord = S.ord;
+    const uint32_t i0 = t * kRun, lbase = lds_lane_base(t);
     uint32_t uf[kRun], ul[kRun];
     {
         int32_t w[M + kRun];
 #pragma unroll
-        for (int m = 0; m < M + kRun; ++m) w[m] = xs[i0 + m];
+        for (int m = 0; m < M + kRun; ++m) w[m] = xs[lbase + lds_rel(m - M)];
         if (lpc_ok) {
             int32_t cq[M];
 #pragma unroll
             for (int q = 0; q < M; ++q) cq[q] = S.q[q];
             uint32_t bad;
-            if (S.wide) bad = lpc_residual<M, 2>(w, cq, S.shift, ul);
-            else if (sb <= 24) bad = lpc_residual<M, 0>(w, cq, S.shift, ul);
-            else bad = lpc_residual<M, 1>(w, cq, S.shift, ul);
+            if (wide) bad = lpc_residual<M, 2>(w, cq, shift, ul);
+            else if (sb <= 24) bad = lpc_residual<M, 0>(w, cq, shift, ul);
+            else bad = lpc_residual<M, 1>(w, cq, shift, ul);
             // only residuals that will be coded count
             if (bad) {
                 uint32_t coded = 0;
@@ -634,27 +875,26 @@ __global__ __launch_bounds__(NT) void k_enc_analyze(const uint8_t *__restrict__ 
         S.psum[1][t] = sl;
     }
     __syncthreads();
-    const bool use_lpc_search = lpc_ok && !S.lpc_bad;
-    rice_search<NT>(S, o, 0, bs, (uint32_t)fo, uf);
-    if (use_lpc_search) rice_search<NT>(S, o, 1, bs, (uint32_t)ord, ul);
+    const bool use_lpc = lpc_ok && !S.lpc_bad;
+    rice_search_both<NT>(S, o, bs, (uint32_t)fo, (uint32_t)ord, use_lpc, uf, ul);
     __syncthreads();
 
     // ---- choice and plan
     const uint32_t pbits0 = S.method[0] ? 5 : 4, pbits1 = S.method[1] ? 5 : 4;
     const uint32_t fixed_bits = hdr + (uint32_t)fo * (uint32_t)sb + 6 + (pbits0 << S.po[0]) + S.exact[0];
     uint32_t lpc_bits = 0xFFFFFFFFu;
-    if (use_lpc_search)
-        lpc_bits = hdr + (uint32_t)ord * (uint32_t)sb + 9 + (uint32_t)ord * (uint32_t)S.prec + 6 + (pbits1 << S.po[1]) + S.exact[1];
+    if (use_lpc)
+        lpc_bits = hdr + (uint32_t)ord * (uint32_t)sb + 9 + (uint32_t)ord * (uint32_t)prec + 6 + (pbits1 << S.po[1]) + S.exact[1];
     const uint32_t verb_bits = hdr + bs * (uint32_t)sb;
     int type = 2, which = 0;
     uint32_t bits = fixed_bits;
-    if (use_lpc_search && (lpc_bits < fixed_bits || o.force_lpc_order)) { type = 3; which = 1; bits = lpc_bits; }
+    if (use_lpc && (lpc_bits < fixed_bits || o.force_lpc_order)) { type = 3; which = 1; bits = lpc_bits; }
     if (verb_bits < bits && !o.force_lpc_order) { type = 1; bits = verb_bits; }
     if (t == 0) {
         PlanHead h = {};
         h.bits = bits; h.type = (uint8_t)type; h.wasted = (uint8_t)wasted; h.sb = (uint8_t)sb;
         h.order = (uint8_t)(type == 3 ? ord : type == 2 ? fo : 0);
-        h.prec = (uint8_t)(type == 3 ? S.prec : 0); h.shift = (uint8_t)(type == 3 ? S.shift : 0);
+        h.prec = (uint8_t)(type == 3 ? prec : 0); h.shift = (uint8_t)(type == 3 ? shift : 0);
         h.po = (uint8_t)S.po[which]; h.method = (uint8_t)S.method[which];
         *reinterpret_cast<PlanHead *>(plan) = h;
     }
@@ -843,19 +1083,20 @@ __device__ inline void put_bits(uint32_t *buf, uint32_t pos, uint32_t value, uin
 
 template <int M, int NT>
 __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
-                                                 uint32_t n_streams, EncOptsDev o, const uint8_t *__restrict__ plans,
+                                                 uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
+                                                 const uint8_t *__restrict__ plans,
                                                  const FrameRec *__restrict__ frames, uint8_t *__restrict__ out, uint32_t buf_words)
 {
-    extern __shared__ __align__(16) int32_t lds[];   // xs: M + NT * kRun samples, then the bit buffer
+    extern __shared__ __align__(16) int32_t lds[];   // xs: enc_lds_words(NT) (see lds_pos), then the bit buffer
     int32_t *xs = lds;
-    uint32_t *buf = reinterpret_cast<uint32_t *>(lds + M + NT * kRun);
+    uint32_t *buf = reinterpret_cast<uint32_t *>(lds + enc_lds_words(NT));
     __shared__ uint32_t s_w[NT / 64];
     __shared__ int32_t s_q[32];
     __shared__ uint8_t s_k[256];
     const uint32_t t = threadIdx.x;
     const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x);
     if (unit >= o.total_pack) return;
-    const int si = find_enc_stream(streams, n_streams, unit, 1);
+    const int si = find_enc_stream(streams, n_streams, hints, unit, 1);
     const EncStreamDev &st = streams[si];
     const uint32_t C = st.channels, rel = unit - st.pack_begin;
     const uint32_t f = rel / C, ch = rel - f * C;
@@ -875,12 +1116,20 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
     const uint32_t smask = sb >= 32 ? 0xFFFFFFFFu : (1u << sb) - 1;
 
     for (uint32_t i = t; i < nwords + 1 && i < buf_words; i += NT) buf[i] = 0;
+    {
+        int32_t v[kRun];
 #pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-        const uint32_t i = t + (uint32_t)j * NT;
-        xs[M + i] = i < bs ? cand_sample(src, i, (int)C, B, (int)cand, stereo4) >> wasted : 0;
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t + (uint32_t)j * NT;
+            v[j] = cand_sample(src, i < bs ? i : bs - 1, (int)C, B, (int)cand, stereo4);
+        }
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t + (uint32_t)j * NT;
+            xs[lds_pos(kFront + i)] = i < bs ? v[j] >> wasted : 0;
+        }
     }
-    if (t < (uint32_t)M) xs[t] = 0;
+    if (t < lds_lane_base(0)) xs[t] = 0;
     if (t < 32) s_q[t] = type == 3 ? (int32_t)reinterpret_cast<const int16_t *>(plan + kPlanHeadBytes)[t] : 0;
     if (type >= 2) for (uint32_t p = t; p < (1u << ph.po); p += NT) s_k[p] = plan[kPlanHeadBytes + kPlanCoefBytes + p];
     __syncthreads();
@@ -892,17 +1141,17 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
         if (wasted) put_bits(buf, pos + 8 + (uint32_t)wasted - 1, 1, 1);
     }
     pos += 8 + (uint32_t)wasted;
-    const uint32_t i0 = t * kRun;
+    const uint32_t i0 = t * kRun, lbase = lds_lane_base(t);
     if (type == 0) {
-        if (t == 0) put_bits(buf, pos, (uint32_t)xs[M] & smask, (uint32_t)sb);
+        if (t == 0) put_bits(buf, pos, (uint32_t)xs[lds_lane_base(0)] & smask, (uint32_t)sb);
     } else if (type == 1) {
 #pragma unroll
         for (int j = 0; j < kRun; ++j) {
             const uint32_t i = i0 + j;
-            if (i < bs) put_bits(buf, pos + i * (uint32_t)sb, (uint32_t)xs[M + i] & smask, (uint32_t)sb);
+            if (i < bs) put_bits(buf, pos + i * (uint32_t)sb, (uint32_t)xs[lbase + j] & smask, (uint32_t)sb);
         }
     } else {
-        if (t < (uint32_t)order) put_bits(buf, pos + t * (uint32_t)sb, (uint32_t)xs[M + t] & smask, (uint32_t)sb);
+        if (t < (uint32_t)order) put_bits(buf, pos + t * (uint32_t)sb, (uint32_t)xs[lds_pos(kFront + t)] & smask, (uint32_t)sb);
         pos += (uint32_t)order * (uint32_t)sb;
         if (type == 3) {
             const uint32_t prec = ph.prec;
@@ -918,7 +1167,7 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
         {
             int32_t w[M + kRun];
 #pragma unroll
-            for (int m = 0; m < M + kRun; ++m) w[m] = xs[i0 + m];
+            for (int m = 0; m < M + kRun; ++m) w[m] = xs[lbase + lds_rel(m - M)];
             if (type == 3) {
                 int32_t cq[M];
 #pragma unroll

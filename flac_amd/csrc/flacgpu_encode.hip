@@ -2,7 +2,8 @@
 // sequencing and the encode entry points of include/flacgpu.h.
 //
 // An encode call runs on one HIP stream:
-//   analyze (workgroup per frame x candidate channel) -> layout (workgroup per stream) ->
+//   stats (workgroup per frame x candidate channel) -> design (lane per candidate) -> choose (workgroup per
+//   candidate) -> layout (workgroup per stream) ->
 //   pack (workgroup per frame x channel) -> CRC-16 of every frame -> CRC bytes,
 // with the optional MD5 kernel beside them on a second stream.  Nothing is read back in between:
 // frame sizes, offsets and stereo decisions stay on the device.
@@ -46,20 +47,28 @@ int encode_init(flacgpu_handle *h)
 }
 
 template <int M, int NT>
-int launch_analyze(flacgpu_handle *h, uint32_t grid, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s,
-                   uint32_t n, const EncOptsDev &o, const float *win, uint8_t *plans)
+int launch_analysis(flacgpu_handle *h, uint32_t grid, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s,
+                    uint32_t n, const uint32_t *hints, const EncOptsDev &o, const float *win, uint8_t *stats, uint8_t *plans,
+                    bool timing)
 {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_analyze<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_enc_analyze<M, NT><<<grid, NT, lds, st>>>(pcm, s, n, o, win, plans);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_stats<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_choose<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_enc_stats<M, NT><<<grid, NT, lds, st>>>(pcm, s, n, hints, o, win, stats, plans);
+    if (timing) HIP_TRY(hipEventRecord(h->eev[EE_STATS], st));
+    k_enc_design<M><<<(o.total_units + 63) / 64, 64, 0, st>>>(s, n, hints, o, stats);
+    if (timing) HIP_TRY(hipEventRecord(h->eev[EE_DESIGN], st));
+    k_enc_choose<M, NT><<<grid, NT, lds, st>>>(pcm, s, n, hints, o, stats, plans);
+    if (timing) HIP_TRY(hipEventRecord(h->eev[EE_CHOOSE], st));
     return FLACGPU_OK;
 }
 
 template <int M, int NT>
 int launch_pack(flacgpu_handle *h, uint32_t grid, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s, uint32_t n,
-                const EncOptsDev &o, const uint8_t *plans, const FrameRec *frames, uint8_t *out, uint32_t buf_words)
+                const uint32_t *hints, const EncOptsDev &o, const uint8_t *plans, const FrameRec *frames, uint8_t *out,
+                uint32_t buf_words)
 {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_pack<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_enc_pack<M, NT><<<grid, NT, lds, st>>>(pcm, s, n, o, plans, frames, out, buf_words);
+    k_enc_pack<M, NT><<<grid, NT, lds, st>>>(pcm, s, n, hints, o, plans, frames, out, buf_words);
     return FLACGPU_OK;
 }
 
@@ -69,7 +78,7 @@ namespace flacgpu {
 
 void encode_release(flacgpu_handle *h)
 {
-    DevBuf *all[] = {&h->e_streams, &h->e_plans, &h->e_frames, &h->e_crc_off, &h->e_crc_len, &h->e_crc, &h->e_windows, &h->e_md5_T};
+    DevBuf *all[] = {&h->e_streams, &h->e_plans, &h->e_frames, &h->e_crc_off, &h->e_crc_len, &h->e_crc, &h->e_windows, &h->e_md5_T, &h->e_stats, &h->e_hints};
     for (DevBuf *b : all) release(*b);
     for (int i = 0; i < EE_COUNT; ++i)
         if (h->eev[i]) (void)hipEventDestroy(h->eev[i]);
@@ -169,6 +178,26 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     o.plan_stride = (uint32_t)((kPlanHeadBytes + kPlanCoefBytes + (1u << opts->max_partition_order) + 15) & ~15u);
     o.total_units = (uint32_t)units; o.total_pack = (uint32_t)pack_units; o.total_frames = (uint32_t)frames;
 
+    // kernel geometry: predictor window (12 or 32 taps) and lanes per block (16 samples each)
+    const uint32_t need_order = std::max(opts->max_lpc_order, opts->force_lpc_order);
+    const int M = need_order <= 12 ? 12 : 32;
+    const int NT = B <= 4096 ? 256 : 1024;
+    // hints[k]: the stream that owns plan unit (first table) / pack unit (second table) k << 10
+    const size_t nh_a = (size_t)(units >> 10) + 2, nh_p = (size_t)(pack_units >> 10) + 2;
+    std::vector<uint32_t> hints(nh_a + nh_p);
+    {
+        uint32_t sa = 0, sp = 0;
+        for (size_t k = 0; k < nh_a; ++k) {
+            while (sa + 1 < n_streams && hs[sa + 1].unit_begin <= (uint64_t)k << 10) ++sa;
+            hints[k] = sa;
+        }
+        for (size_t k = 0; k < nh_p; ++k) {
+            while (sp + 1 < n_streams && hs[sp + 1].pack_begin <= (uint64_t)k << 10) ++sp;
+            hints[nh_a + k] = sp;
+        }
+    }
+    if ((rc = reserve(h, h->e_hints, hints.size() * 4))) return rc;
+    if ((rc = reserve(h, h->e_stats, (size_t)std::max<uint64_t>(units, 1) * stats_stride(M)))) return rc;
     if ((rc = reserve(h, h->e_streams, (size_t)n_streams * sizeof(EncStreamDev)))) return rc;
     if ((rc = reserve(h, h->e_windows, windows.size() * sizeof(float) + 16))) return rc;
     if ((rc = reserve(h, h->e_plans, (size_t)std::max<uint64_t>(units, 1) * o.plan_stride))) return rc;
@@ -177,6 +206,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     if ((rc = reserve(h, h->e_crc_len, (size_t)std::max<uint64_t>(frames, 1) * 4))) return rc;
     if ((rc = reserve(h, h->e_crc, (size_t)std::max<uint64_t>(frames, 1) * 2))) return rc;
     HIP_TRY(hipMemcpyAsync(h->e_streams.p, hs.data(), (size_t)n_streams * sizeof(EncStreamDev), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->e_hints.p, hints.data(), hints.size() * 4, hipMemcpyHostToDevice, st));
     if (!windows.empty())
         HIP_TRY(hipMemcpyAsync(h->e_windows.p, windows.data(), windows.size() * sizeof(float), hipMemcpyHostToDevice, st));
 
@@ -191,32 +221,30 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     }
     if (timing) HIP_TRY(hipEventRecord(h->eev[EE_START], st));
 
-    // ---- kernel geometry: predictor window (12 or 32 taps) and lanes per block (16 samples each)
-    const uint32_t need_order = std::max(opts->max_lpc_order, opts->force_lpc_order);
-    const int M = need_order <= 12 ? 12 : 32;
-    const int NT = B <= 4096 ? 256 : 1024;
-    const size_t xs_bytes = (size_t)(M + NT * kRun) * 4;
+    const size_t xs_bytes = (size_t)enc_lds_words(NT) * 4;
     const uint32_t buf_words = (31 + 8 + 32 + B * (max_bps + 1) + 31) / 32 + 2;
     const size_t pack_lds = xs_bytes + (size_t)buf_words * 4;
     const uint32_t grid_a = (uint32_t)((units + 7) / 8 * 8), grid_p = (uint32_t)((pack_units + 7) / 8 * 8);
     const float *win = (const float *)h->e_windows.p;
-    uint8_t *plans = (uint8_t *)h->e_plans.p;
+    const uint32_t *hints_a = (const uint32_t *)h->e_hints.p, *hints_p = hints_a + nh_a;
+    uint8_t *plans = (uint8_t *)h->e_plans.p, *stats = (uint8_t *)h->e_stats.p;
     FrameRec *fr = (FrameRec *)h->e_frames.p;
     if (units) {
-        if (M == 12 && NT == 256) rc = launch_analyze<12, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, o, win, plans);
-        else if (M == 32 && NT == 256) rc = launch_analyze<32, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, o, win, plans);
-        else if (M == 12) rc = launch_analyze<12, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, o, win, plans);
-        else rc = launch_analyze<32, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, o, win, plans);
+        if (M == 12 && NT == 256) rc = launch_analysis<12, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing);
+        else if (M == 32 && NT == 256) rc = launch_analysis<32, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing);
+        else if (M == 12) rc = launch_analysis<12, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing);
+        else rc = launch_analysis<32, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing);
         if (rc) return rc;
+    } else if (timing) {
+        HIP_TRY(hipEventRecord(h->eev[EE_STATS], st)); HIP_TRY(hipEventRecord(h->eev[EE_DESIGN], st)); HIP_TRY(hipEventRecord(h->eev[EE_CHOOSE], st));
     }
-    if (timing) HIP_TRY(hipEventRecord(h->eev[EE_ANALYZE], st));
     k_enc_layout<<<n_streams, 256, 0, st>>>(ds, o, plans, fr, (uint64_t *)h->e_crc_off.p, (uint32_t *)h->e_crc_len.p, out, md5 ? 1 : 0);
     if (timing) HIP_TRY(hipEventRecord(h->eev[EE_LAYOUT], st));
     if (pack_units) {
-        if (M == 12 && NT == 256) rc = launch_pack<12, 256>(h, grid_p, pack_lds, st, pcm, ds, n_streams, o, plans, fr, out, buf_words);
-        else if (M == 32 && NT == 256) rc = launch_pack<32, 256>(h, grid_p, pack_lds, st, pcm, ds, n_streams, o, plans, fr, out, buf_words);
-        else if (M == 12) rc = launch_pack<12, 1024>(h, grid_p, pack_lds, st, pcm, ds, n_streams, o, plans, fr, out, buf_words);
-        else rc = launch_pack<32, 1024>(h, grid_p, pack_lds, st, pcm, ds, n_streams, o, plans, fr, out, buf_words);
+        if (M == 12 && NT == 256) rc = launch_pack<12, 256>(h, grid_p, pack_lds, st, pcm, ds, n_streams, hints_p, o, plans, fr, out, buf_words);
+        else if (M == 32 && NT == 256) rc = launch_pack<32, 256>(h, grid_p, pack_lds, st, pcm, ds, n_streams, hints_p, o, plans, fr, out, buf_words);
+        else if (M == 12) rc = launch_pack<12, 1024>(h, grid_p, pack_lds, st, pcm, ds, n_streams, hints_p, o, plans, fr, out, buf_words);
+        else rc = launch_pack<32, 1024>(h, grid_p, pack_lds, st, pcm, ds, n_streams, hints_p, o, plans, fr, out, buf_words);
         if (rc) return rc;
     }
     if (timing) HIP_TRY(hipEventRecord(h->eev[EE_PACK], st));
@@ -246,8 +274,10 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     t.frames = frames; t.in_bytes = in_total; t.out_bytes = out_total;
     if (timing) {
         auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, h->eev[a], h->eev[b]); return ms; };
-        t.analyze_ms = el(EE_START, EE_ANALYZE);
-        t.layout_ms = el(EE_ANALYZE, EE_LAYOUT);
+        t.stats_ms = el(EE_START, EE_STATS);
+        t.design_ms = el(EE_STATS, EE_DESIGN);
+        t.choose_ms = el(EE_DESIGN, EE_CHOOSE);
+        t.layout_ms = el(EE_CHOOSE, EE_LAYOUT);
         t.pack_ms = el(EE_LAYOUT, EE_PACK);
         t.crc_ms = el(EE_PACK, EE_CRC);
         t.total_ms = el(EE_START, EE_END);

@@ -19,7 +19,7 @@ struct DevBuf {
 };
 
 enum { EV_START, EV_SCAN, EV_COMPACT, EV_CRC, EV_RESOLVE, EV_SKIM, EV_DECODE, EV_RESULTS, EV_COUNT };
-enum { EE_START, EE_ANALYZE, EE_LAYOUT, EE_PACK, EE_CRC, EE_END, EE_MD5_START, EE_MD5_END, EE_COUNT };
+enum { EE_START, EE_STATS, EE_DESIGN, EE_CHOOSE, EE_LAYOUT, EE_PACK, EE_CRC, EE_END, EE_MD5_START, EE_MD5_END, EE_COUNT };
 
 }  // namespace flacgpu
 
@@ -37,7 +37,7 @@ struct flacgpu_handle {
     std::vector<flacgpu::StreamDev> h_streams;
     uint32_t n_cand = 0;   // state of the last scan, used by flacgpu_scan_frames
     // encode
-    flacgpu::DevBuf e_streams, e_plans, e_frames, e_crc_off, e_crc_len, e_crc, e_windows, e_md5_T;
+    flacgpu::DevBuf e_streams, e_plans, e_frames, e_crc_off, e_crc_len, e_crc, e_windows, e_md5_T, e_stats, e_hints;
     hipStream_t md5_stream = nullptr;
     hipEvent_t eev[flacgpu::EE_COUNT] = {};
     flacgpu_encode_timing enc_timing = {};

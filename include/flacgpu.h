@@ -280,7 +280,9 @@ typedef struct flacgpu_encode_result {
 
 /* Device time of the last encode call, milliseconds (FLACGPU_FLAG_TIMING). */
 typedef struct flacgpu_encode_timing {
-    float analyze_ms;    /* predictor search per candidate channel                    */
+    float stats_ms;      /* per candidate channel: fixed-predictor errors, autocorrelation */
+    float design_ms;     /* Levinson-Durbin, order choice, coefficient quantisation   */
+    float choose_ms;     /* residuals, Rice partition search, cheapest subframe       */
     float layout_ms;     /* stereo decisions, frame sizes and offsets, headers        */
     float pack_ms;       /* residual coding and bit packing                           */
     float crc_ms;        /* CRC-16 of every frame                                     */
