@@ -415,13 +415,13 @@ template <int M, int NT>
 __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
                                                   uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
                                                   const float *__restrict__ windows, uint8_t *__restrict__ stats,
-                                                  uint8_t *__restrict__ plans)
+                                                  uint8_t *__restrict__ plans, uint32_t unit_base, uint32_t unit_end)
 {
     extern __shared__ __align__(16) int32_t xs[];   // enc_lds_words(NT): see lds_pos
     __shared__ StatsShared<NT> S;
     const uint32_t t = threadIdx.x, lane = t & 63;
-    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x);
-    if (unit >= o.total_units) return;
+    const uint32_t unit = unit_base + xcd_unit(blockIdx.x, gridDim.x);
+    if (unit >= unit_end) return;
     const UnitInfo u = unit_info(pcm, streams, n_streams, hints, o, unit);
     const uint32_t bs = u.bs;
     const float *win = windows + (u.last ? u.st->win_off_tail : u.st->win_off);
@@ -794,13 +794,14 @@ __device__ inline void rice_search_both(ChooseShared<NT> &S, const EncOptsDev &o
 template <int M, int NT>
 __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
                                                    uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
-                                                   const uint8_t *__restrict__ stats, uint8_t *__restrict__ plans)
+                                                   const uint8_t *__restrict__ stats, uint8_t *__restrict__ plans,
+                                                   uint32_t unit_base, uint32_t unit_end)
 {
     extern __shared__ __align__(16) int32_t xs[];   // enc_lds_words(NT): see lds_pos
     __shared__ ChooseShared<NT> S;
     const uint32_t t = threadIdx.x;
-    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x);
-    if (unit >= o.total_units) return;
+    const uint32_t unit = unit_base + xcd_unit(blockIdx.x, gridDim.x);
+    if (unit >= unit_end) return;
     const CandStats *cs = reinterpret_cast<const CandStats *>(stats + (uint64_t)unit * stats_stride(M));
     if (cs->constant) return;
     const UnitInfo u = unit_info(pcm, streams, n_streams, hints, o, unit);
@@ -1085,7 +1086,8 @@ template <int M, int NT>
 __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
                                                  uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
                                                  const uint8_t *__restrict__ plans,
-                                                 const FrameRec *__restrict__ frames, uint8_t *__restrict__ out, uint32_t buf_words)
+                                                 const FrameRec *__restrict__ frames, uint8_t *__restrict__ out, uint32_t buf_words,
+                                                 uint32_t unit_base, uint32_t unit_end)
 {
     extern __shared__ __align__(16) int32_t lds[];   // xs: enc_lds_words(NT) (see lds_pos), then the bit buffer
     int32_t *xs = lds;
@@ -1094,8 +1096,8 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
     __shared__ int32_t s_q[32];
     __shared__ uint8_t s_k[256];
     const uint32_t t = threadIdx.x;
-    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x);
-    if (unit >= o.total_pack) return;
+    const uint32_t unit = unit_base + xcd_unit(blockIdx.x, gridDim.x);
+    if (unit >= unit_end) return;
     const int si = find_enc_stream(streams, n_streams, hints, unit, 1);
     const EncStreamDev &st = streams[si];
     const uint32_t C = st.channels, rel = unit - st.pack_begin;

@@ -47,28 +47,43 @@ int encode_init(flacgpu_handle *h)
 }
 
 template <int M, int NT>
-int launch_analysis(flacgpu_handle *h, uint32_t grid, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s,
+int launch_analysis(flacgpu_handle *h, uint32_t, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s,
                     uint32_t n, const uint32_t *hints, const EncOptsDev &o, const float *win, uint8_t *stats, uint8_t *plans,
                     bool timing)
 {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_stats<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_choose<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_enc_stats<M, NT><<<grid, NT, lds, st>>>(pcm, s, n, hints, o, win, stats, plans);
+    // a launch holds fewer than 2^32 work-items, so large batches go in several launches
+    const uint32_t chunk = (0xF0000000u / NT) & ~7u;
+    for (uint32_t b = 0; b < o.total_units; b += chunk) {
+        const uint32_t e = o.total_units - b < chunk ? o.total_units : b + chunk;
+        k_enc_stats<M, NT><<<(e - b + 7) / 8 * 8, NT, lds, st>>>(pcm, s, n, hints, o, win, stats, plans, b, e);
+    }
+    HIP_TRY(hipGetLastError());
     if (timing) HIP_TRY(hipEventRecord(h->eev[EE_STATS], st));
     k_enc_design<M><<<(o.total_units + 63) / 64, 64, 0, st>>>(s, n, hints, o, stats);
     if (timing) HIP_TRY(hipEventRecord(h->eev[EE_DESIGN], st));
-    k_enc_choose<M, NT><<<grid, NT, lds, st>>>(pcm, s, n, hints, o, stats, plans);
+    for (uint32_t b = 0; b < o.total_units; b += chunk) {
+        const uint32_t e = o.total_units - b < chunk ? o.total_units : b + chunk;
+        k_enc_choose<M, NT><<<(e - b + 7) / 8 * 8, NT, lds, st>>>(pcm, s, n, hints, o, stats, plans, b, e);
+    }
+    HIP_TRY(hipGetLastError());
     if (timing) HIP_TRY(hipEventRecord(h->eev[EE_CHOOSE], st));
     return FLACGPU_OK;
 }
 
 template <int M, int NT>
-int launch_pack(flacgpu_handle *h, uint32_t grid, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s, uint32_t n,
+int launch_pack(flacgpu_handle *h, uint32_t, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s, uint32_t n,
                 const uint32_t *hints, const EncOptsDev &o, const uint8_t *plans, const FrameRec *frames, uint8_t *out,
                 uint32_t buf_words)
 {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_pack<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_enc_pack<M, NT><<<grid, NT, lds, st>>>(pcm, s, n, hints, o, plans, frames, out, buf_words);
+    const uint32_t chunk = (0xF0000000u / NT) & ~7u;
+    for (uint32_t b = 0; b < o.total_pack; b += chunk) {
+        const uint32_t e = o.total_pack - b < chunk ? o.total_pack : b + chunk;
+        k_enc_pack<M, NT><<<(e - b + 7) / 8 * 8, NT, lds, st>>>(pcm, s, n, hints, o, plans, frames, out, buf_words, b, e);
+    }
+    HIP_TRY(hipGetLastError());
     return FLACGPU_OK;
 }
 
