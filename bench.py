@@ -227,6 +227,18 @@ def main():
         got = d_out[i * out_stride: i * out_stride + pcm_bytes_per_file].cpu().numpy()
         assert hashlib.md5(got.tobytes()).hexdigest() == infos[i % unique].md5_signature, f"MD5 mismatch, stream {i}"
 
+    md5_check = None
+    if check:
+        # every stream's PCM against its STREAMINFO signature, hashed where it lies (one GPU lane per stream)
+        t0 = time.perf_counter()
+        digests = dec.md5_batch_device(d_out, out_bytes, [i * out_stride for i in range(nfiles)], [pcm_bytes_per_file] * nfiles,
+                                       hip_stream=hip_stream)
+        wrong = [i for i in range(nfiles) if digests[i] != bytes(infos[i % unique].md5)]
+        assert not wrong, f"{len(wrong)} streams differ from their STREAMINFO MD5 (first: {wrong[:4]})"
+        md5_check = {"streams": nfiles, "seconds": time.perf_counter() - t0}
+        if rank == 0:
+            log(f"MD5 of all {nfiles} decoded streams equals STREAMINFO ({md5_check['seconds']:.2f} s on the device)")
+
     kernel_ms = {k: 0.0 for k in ("scan_ms", "compact_ms", "crc16_ms", "resolve_ms", "skim_ms", "decode_ms", "results_ms", "total_ms")}
     barrier()
     torch.cuda.synchronize(dev)
@@ -335,6 +347,7 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms["decode_ms"]},
             "cpu_baseline": cpu,
+            "md5_verified": md5_check,
             "encode": enc,
         }
         print(json.dumps(out), flush=True)

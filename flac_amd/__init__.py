@@ -145,6 +145,7 @@ EXPORTS = [
     "flacgpu_status_string", "flacgpu_create", "flacgpu_destroy", "flacgpu_last_error", "flacgpu_scan_frames",
     "flacgpu_decode_batch_device", "flacgpu_decode_batch", "flacgpu_get_timing",
     "flacgpu_encode_bound", "flacgpu_encode_batch_device", "flacgpu_encode_batch", "flacgpu_get_encode_timing",
+    "flacgpu_md5_batch_device",
 ]
 
 _lib = None
@@ -200,6 +201,8 @@ def lib():
                                            ctypes.POINTER(EncodeOptions), ctypes.POINTER(vp), ctypes.POINTER(u64),
                                            ctypes.POINTER(EncodeResult)]
         L.flacgpu_get_encode_timing.argtypes = [vp, ctypes.POINTER(EncodeTiming)]
+        L.flacgpu_md5_batch_device.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), u32,
+                                               ctypes.c_void_p, vp]
         _lib = L
     return _lib
 
@@ -371,6 +374,17 @@ class Decoder:
         rc = lib().flacgpu_encode_batch(self._h, iptr, streams, n, ctypes.byref(opts), optr, ocap, res)
         self._check(rc)
         return [o[: int(r.out_length)] for o, r in zip(outs, res)], list(res)
+
+    def md5_batch_device(self, d_buf, buf_bytes, offsets, lengths, hip_stream=0):
+        """MD5 of byte ranges of a device buffer (one GPU lane per range).  Returns a list of 16-byte digests."""
+        n = len(offsets)
+        offs = (ctypes.c_uint64 * n)(*[int(o) for o in offsets])
+        lens = (ctypes.c_uint64 * n)(*[int(x) for x in lengths])
+        out = np.zeros(16 * n, dtype=np.uint8)
+        rc = lib().flacgpu_md5_batch_device(self._h, _ptr(d_buf), buf_bytes, offs, lens, n, out.ctypes.data,
+                                            hip_stream or None)
+        self._check(rc)
+        return [out[16 * i: 16 * i + 16].tobytes() for i in range(n)]
 
     def encode_timing(self) -> EncodeTiming:
         t = EncodeTiming()

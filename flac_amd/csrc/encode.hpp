@@ -1249,19 +1249,9 @@ __device__ inline void md5_block(uint32_t (&h)[4], const uint32_t (&w)[16], cons
     h[0] += a; h[1] += b; h[2] += c; h[3] += d;
 }
 
-// MD5 of each stream's packed PCM (the STREAMINFO signature, flacmeta.go:714), one lane per stream.
-// T: the 64 sine-derived constants of RFC 1321.
-__global__ __launch_bounds__(64) void k_enc_md5(const uint8_t *__restrict__ pcm, EncStreamDev *__restrict__ streams, uint32_t n,
-                                                const uint32_t *__restrict__ T, uint8_t *__restrict__ out)
+// MD5 (RFC 1321) of len bytes at p, by one lane.  T: the 64 sine-derived constants, in LDS.
+__device__ inline void md5_bytes(const uint8_t *p, uint64_t len, const uint32_t *T, uint8_t *digest)
 {
-    __shared__ uint32_t s_T[64];
-    s_T[threadIdx.x] = T[threadIdx.x];
-    __syncthreads();
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= n) return;
-    EncStreamDev &st = streams[s];
-    const uint64_t len = st.total_samples * st.channels * st.bytes_ps;
-    const uint8_t *p = pcm + st.in_off;
     uint32_t h[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
     const bool aligned = (((uintptr_t)p) & 15) == 0;
     uint64_t done = 0;
@@ -1280,7 +1270,7 @@ __global__ __launch_bounds__(64) void k_enc_md5(const uint8_t *__restrict__ pcm,
                 w[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
             }
         }
-        md5_block(h, w, s_T);
+        md5_block(h, w, T);
     }
     // tail: remaining bytes, 0x80, zeros, 64-bit length in bits
     const uint32_t rem = (uint32_t)(len - done);
@@ -1301,13 +1291,39 @@ __global__ __launch_bounds__(64) void k_enc_md5(const uint8_t *__restrict__ pcm,
         }
         const bool lastblk = (blk == 0 && rem < 56) || blk == 1;
         if (lastblk) { w[14] = (uint32_t)bits; w[15] = (uint32_t)(bits >> 32); }
-        md5_block(h, w, s_T);
+        md5_block(h, w, T);
         if (lastblk) break;
     }
     for (int q = 0; q < 4; ++q)
-        for (int b = 0; b < 4; ++b) st.md5[4 * q + b] = (uint8_t)(h[q] >> (8 * b));
+        for (int b = 0; b < 4; ++b) digest[4 * q + b] = (uint8_t)(h[q] >> (8 * b));
+}
+
+// MD5 of each stream's packed PCM (the STREAMINFO signature, flacmeta.go:714), one lane per stream.
+__global__ __launch_bounds__(64) void k_enc_md5(const uint8_t *__restrict__ pcm, EncStreamDev *__restrict__ streams, uint32_t n,
+                                                const uint32_t *__restrict__ T, uint8_t *__restrict__ out)
+{
+    __shared__ uint32_t s_T[64];
+    s_T[threadIdx.x] = T[threadIdx.x];
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    EncStreamDev &st = streams[s];
+    md5_bytes(pcm + st.in_off, st.total_samples * st.channels * st.bytes_ps, s_T, st.md5);
     if (out && st.out_cap >= 42)
         for (int q = 0; q < 16; ++q) out[st.out_off + 26 + q] = st.md5[q];
+}
+
+// MD5 of n byte ranges [off[i], off[i] + len[i]) of base, one lane per range; digests to out[16 * i].
+__global__ __launch_bounds__(64) void k_md5_ranges(const uint8_t *__restrict__ base, const uint64_t *__restrict__ off,
+                                                   const uint64_t *__restrict__ len, uint32_t n, const uint32_t *__restrict__ T,
+                                                   uint8_t *__restrict__ out)
+{
+    __shared__ uint32_t s_T[64];
+    s_T[threadIdx.x] = T[threadIdx.x];
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    md5_bytes(base + off[s], len[s], s_T, out + 16ull * s);
 }
 
 }  // namespace flacgpu

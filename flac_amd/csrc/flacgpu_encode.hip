@@ -302,6 +302,30 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     return FLACGPU_OK;
 }
 
+int flacgpu_md5_batch_device(flacgpu_handle *h, const void *d_buf, uint64_t buf_bytes, const uint64_t *offsets,
+                             const uint64_t *lengths, uint32_t n, uint8_t *digests, void *hip_stream)
+{
+    if (!h || !d_buf || !offsets || !lengths || !n || !digests) return fail(h, FLACGPU_ERR_ARG, "null argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (offsets[i] > buf_bytes || lengths[i] > buf_bytes - offsets[i]) return fail(h, FLACGPU_ERR_ARG, "range exceeds the buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = encode_init(h);
+    if (rc) return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    // workspace: offsets, lengths, digests
+    if ((rc = reserve(h, h->e_crc_off, (size_t)n * 8))) return rc;
+    if ((rc = reserve(h, h->e_stats, (size_t)n * 8))) return rc;
+    if ((rc = reserve(h, h->e_crc, (size_t)n * 16))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->e_crc_off.p, offsets, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->e_stats.p, lengths, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    k_md5_ranges<<<(n + 63) / 64, 64, 0, st>>>((const uint8_t *)d_buf, (const uint64_t *)h->e_crc_off.p, (const uint64_t *)h->e_stats.p, n,
+                                               (const uint32_t *)h->e_md5_T.p, (uint8_t *)h->e_crc.p);
+    HIP_TRY(hipMemcpyAsync(digests, h->e_crc.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    return FLACGPU_OK;
+}
+
 int flacgpu_encode_batch(flacgpu_handle *h, const uint8_t *const *pcm, const flacgpu_pcm_stream *streams, uint32_t n_streams,
                          const flacgpu_encode_options *opts, uint8_t *const *out, const uint64_t *out_caps,
                          flacgpu_encode_result *results)

@@ -315,6 +315,15 @@ int flacgpu_encode_batch(flacgpu_handle *h, const uint8_t *const *pcm, const fla
 
 int flacgpu_get_encode_timing(const flacgpu_handle *h, flacgpu_encode_timing *out);
 
+/* MD5 of n byte ranges of a device buffer, one GPU lane per range: the check of
+ * decoded PCM against StreaminfoBlock.MD5Signature (flacmeta.go:664, :714)
+ * without copying the PCM to the host.  offsets / lengths: host arrays, bytes
+ * from d_buf; digests: host array of 16 * n bytes.  MD5 is a serial chain, so
+ * this pays off for many ranges (one per stream), not for one long range. */
+int flacgpu_md5_batch_device(flacgpu_handle *h, const void *d_buf, uint64_t buf_bytes,
+                             const uint64_t *offsets, const uint64_t *lengths, uint32_t n,
+                             uint8_t *digests, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,31 @@ def test_long_rice_codes(decoder):
         assert bytes(want) == src
         assert np.array_equal(p, want)
         assert r.frames_ok == ost.frames_ok == 4
+
+
+def test_device_md5_matches_streaminfo(decoder, testdata):
+    """flacgpu_md5_batch_device on the decoded PCM still in HBM: equals hashlib and the STREAMINFO
+    signatures the reference's tests assert (flacmeta_test.go:37, :121), for lengths around the 64-byte
+    block and 56-byte padding boundaries too."""
+    import hashlib
+    import torch
+    rng = np.random.default_rng(3)
+    lens = [0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 128, 1000, 4096, 100003]
+    blob = rng.integers(0, 256, size=sum((n + 19) for n in lens) + 64, dtype=np.uint8)
+    offs, pos = [], 3                      # unaligned starts as well
+    for n in lens:
+        offs.append(pos)
+        pos += n + 19
+    d = torch.from_numpy(blob).cuda()
+    got = decoder.md5_batch_device(d, blob.size, offs, lens)
+    for o, n, g in zip(offs, lens, got):
+        assert g == hashlib.md5(blob[o:o + n].tobytes()).digest(), n
+    files = [_read(testdata, MONO), _read(testdata, STEREO)]
+    infos = [split_file(f)[0] for f in files]
+    pcms, res, _ = gpu_batch(decoder, files)
+    cat = np.concatenate([np.zeros(16, np.uint8)] + pcms)
+    d = torch.from_numpy(cat).cuda()
+    o2 = [16, 16 + pcms[0].size]
+    got = decoder.md5_batch_device(d, cat.size, o2, [p.size for p in pcms])
+    assert [g.hex() for g in got] == [si.md5_signature for si in infos]
+    assert got[0].hex() == "e5ccc967ced6c111530e5c79e33c969e" and got[1].hex() == "6291dbd8dcb7dc480132e4c4ba154a17"
