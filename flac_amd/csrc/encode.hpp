@@ -234,6 +234,38 @@ __device__ inline int32_t cand_sample(const uint8_t *src, uint32_t i, int C, int
     return load_le(src + ((size_t)i * C + cand) * B, B);
 }
 
+// The lane's share of a block as it is loaded: samples t, t + NT, t + 2 NT, ... (consecutive lanes read
+// consecutive samples).  Every load is issued, with the index clamped into the block, so that the 16 of them
+// overlap; samples beyond the block come back as zero.  16-bit stereo, the common case, has its own loop.
+template <int NT>
+__device__ inline void load_block_share(const uint8_t *src, uint32_t bs, int C, int B, int cand, bool stereo, int32_t (&v)[kRun])
+{
+    const uint32_t t = threadIdx.x;
+    if (stereo && B == 2) {
+        uint32_t lr[kRun];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t + (uint32_t)j * NT;
+            lr[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)(i < bs ? i : bs - 1) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const int32_t l = (int32_t)(lr[j] << 16) >> 16, r = (int32_t)lr[j] >> 16;
+            const int32_t x = cand == 0 ? l : cand == 1 ? r : cand == 2 ? (l + r) >> 1 : l - r;
+            v[j] = t + (uint32_t)j * NT < bs ? x : 0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t + (uint32_t)j * NT;
+            v[j] = cand_sample(src, i < bs ? i : bs - 1, C, B, cand, stereo);
+        }
+#pragma unroll
+        for (int j = 0; j < kRun; ++j)
+            if (t + (uint32_t)j * NT >= bs) v[j] = 0;
+    }
+}
+
 // Stream that owns plan unit (which = 0) or pack unit (which = 1) idx.  hints[k] is the owner of unit k << 10
 // (built on the host), so the search runs over the few streams between two hints.
 __device__ inline int find_enc_stream(const EncStreamDev *s, uint32_t n, const uint32_t *hints, uint32_t idx, int which)
@@ -328,12 +360,29 @@ __device__ inline void fixed_residual(const int32_t (&w)[M + kRun], int order, u
     }
 }
 
-// LPC residual.  MODE 0: 24-bit multiplies (samples of at most 24 bits, coefficients of at most 15),
-// 1: 32-bit wrapping sums, 2: 64-bit sums.  Bit j of the result is set when residual j does not fit 32 bits.
+__device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
+{
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Bits [lo, hi) of a lane's 16-sample run, as a mask: the samples i0 + j with first <= i0 + j < end.
+__device__ inline uint32_t run_mask(uint32_t i0, uint32_t first, uint32_t end)
+{
+    const uint32_t lo = first > i0 ? (first - i0 > (uint32_t)kRun ? (uint32_t)kRun : first - i0) : 0;
+    const uint32_t hi = end > i0 ? (end - i0 > (uint32_t)kRun ? (uint32_t)kRun : end - i0) : 0;
+    return hi > lo ? ((1u << hi) - 1) & ~((1u << lo) - 1) : 0;
+}
+
+// LPC residual.  MODE 0: 24-bit multiply-adds (samples of at most 24 bits, coefficients of at most 15),
+// 1: 32-bit wrapping sums, 2: 64-bit sums.  The result is nonzero when some residual of the run may not
+// fit 32 bits (r + 2^31 - 1 has bits above 31 exactly when r is outside [-(2^31 - 1), 2^31 - 1]); the
+// caller then finds out which with lpc_residual_bad.
 template <int M, int MODE>
 __device__ inline uint32_t lpc_residual(const int32_t (&w)[M + kRun], const int32_t (&cq)[M], int shift, uint32_t (&u)[kRun])
 {
-    uint32_t bad = 0;
+    uint32_t high = 0;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
         int64_t pred;
@@ -342,16 +391,45 @@ __device__ inline uint32_t lpc_residual(const int32_t (&w)[M + kRun], const int3
 #pragma unroll
             for (int q = 0; q < M; ++q) s += (int64_t)cq[q] * (int64_t)w[M + j - 1 - q];
             pred = s >> shift;
-        } else {
+        } else if (MODE == 1) {
             uint32_t s = 0;
 #pragma unroll
-            for (int q = 0; q < M; ++q)
-                s += MODE == 0 ? (uint32_t)__mul24(cq[q], w[M + j - 1 - q]) : (uint32_t)cq[q] * (uint32_t)w[M + j - 1 - q];
+            for (int q = 0; q < M; ++q) s += (uint32_t)cq[q] * (uint32_t)w[M + j - 1 - q];
+            pred = (int32_t)s >> shift;
+        } else {
+            int32_t s0 = 0, s1 = 0;
+#pragma unroll
+            for (int q = 0; q < M; q += 2) {
+                s0 = mad_i24(cq[q], w[M + j - 1 - q], s0);
+                if (q + 1 < M) s1 = mad_i24(cq[q + 1], w[M + j - 2 - q], s1);
+            }
+            pred = (int32_t)((uint32_t)s0 + (uint32_t)s1) >> shift;
+        }
+        const int64_t r = (int64_t)w[M + j] - pred;
+        high |= (uint32_t)((uint64_t)(r + 0x7FFFFFFFLL) >> 32);
+        u[j] = fold((int32_t)r);
+    }
+    return high;
+}
+
+// Which residuals of the run do not fit 32 bits (bit j): the slow restatement of lpc_residual's test.
+template <int M>
+__device__ __noinline__ uint32_t lpc_residual_bad(const int32_t (&w)[M + kRun], const int32_t (&cq)[M], int shift, bool wide)
+{
+    uint32_t bad = 0;
+    for (int j = 0; j < kRun; ++j) {
+        int64_t pred;
+        if (wide) {
+            int64_t s = 0;
+            for (int q = 0; q < M; ++q) s += (int64_t)cq[q] * (int64_t)w[M + j - 1 - q];
+            pred = s >> shift;
+        } else {
+            uint32_t s = 0;
+            for (int q = 0; q < M; ++q) s += (uint32_t)cq[q] * (uint32_t)w[M + j - 1 - q];
             pred = (int32_t)s >> shift;
         }
         const int64_t r = (int64_t)w[M + j] - pred;
         bad |= (uint32_t)((r != (int64_t)(int32_t)r) || (r == -2147483647LL - 1)) << j;
-        u[j] = fold((int32_t)r);
     }
     return bad;
 }
@@ -436,16 +514,10 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
     int32_t v[kRun];
     uint32_t ored = 0, neq = 0;
     const int32_t first = cand_sample(u.src, 0, u.C, u.B, (int)u.cand, u.stereo);
-    // every load is issued (index clamped into the block) so that the 16 of them overlap
+    load_block_share<NT>(u.src, bs, u.C, u.B, (int)u.cand, u.stereo, v);
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
         const uint32_t i = t + (uint32_t)j * NT;
-        v[j] = cand_sample(u.src, i < bs ? i : bs - 1, u.C, u.B, (int)u.cand, u.stereo);
-    }
-#pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-        const uint32_t i = t + (uint32_t)j * NT;
-        if (i >= bs) v[j] = 0;
         ored |= (uint32_t)v[j];
         neq |= i < bs ? (uint32_t)(v[j] ^ first) : 0u;
     }
@@ -479,21 +551,23 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
         for (int m = 0; m < 4 + kRun; ++m) w[m] = xs[lbase + lds_rel(m - 4)];
 #pragma unroll
         for (int j = 0; j < kRun; ++j) mine[j] = w[4 + j];
-        // 8 errors of at most 2^28 fit 32 bits; the two halves of the run are widened and added
+        // 8 errors of at most 2^28 fit 32 bits; the two halves of the run are widened and added.  Only the
+        // first lane (samples 0..3 do not count) and the lanes at the end of the block need the range test.
         uint64_t e64[5] = {0, 0, 0, 0, 0};
+        const uint32_t counted = run_mask(i0, 4, bs);
+        const bool all_counted = __all(counted == 0xFFFFu);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint32_t e32[5] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int jj = 0; jj < kRun / 2; ++jj) {
                 const int j = half * (kRun / 2) + jj;
-                const uint32_t i = i0 + j;
-                if (i >= 4 && i < bs) {
-                    const int32_t a = w[4 + j], b = w[3 + j], c = w[2 + j], d = w[1 + j], e = w[j];
-                    const int32_t d1 = a - b, d2 = a - 2 * b + c, d3 = a - 3 * b + 3 * c - d, d4 = a - 4 * b + 6 * c - 4 * d + e;
-                    e32[0] += (uint32_t)(a < 0 ? -a : a); e32[1] += (uint32_t)(d1 < 0 ? -d1 : d1); e32[2] += (uint32_t)(d2 < 0 ? -d2 : d2);
-                    e32[3] += (uint32_t)(d3 < 0 ? -d3 : d3); e32[4] += (uint32_t)(d4 < 0 ? -d4 : d4);
-                }
+                const int32_t a = w[4 + j], b = w[3 + j], c = w[2 + j], d = w[1 + j], e = w[j];
+                const int32_t d1 = a - b, d2 = a - 2 * b + c, d3 = a - 3 * b + 3 * c - d, d4 = a - 4 * b + 6 * c - 4 * d + e;
+                uint32_t a0 = (uint32_t)(a < 0 ? -a : a), a1 = (uint32_t)(d1 < 0 ? -d1 : d1), a2 = (uint32_t)(d2 < 0 ? -d2 : d2),
+                         a3 = (uint32_t)(d3 < 0 ? -d3 : d3), a4 = (uint32_t)(d4 < 0 ? -d4 : d4);
+                if (!all_counted && !((counted >> j) & 1)) { a0 = 0; a1 = 0; a2 = 0; a3 = 0; a4 = 0; }
+                e32[0] += a0; e32[1] += a1; e32[2] += a2; e32[3] += a3; e32[4] += a4;
             }
 #pragma unroll
             for (int k = 0; k < 5; ++k) e64[k] += e32[k];
@@ -690,12 +764,14 @@ struct ChooseShared {
 };
 
 // Partition search of the residuals of both predictors at once (slot 0 fixed, slot 1 lpc when use1): fills
-// S.po / S.method / S.kb / S.exact.  Called by the whole workgroup.  uf / ul: the lane's folded residuals.
+// S.po / S.method / S.kb / S.exact.  Called by the whole workgroup.  uf / ul: the lane's folded residuals
+// (zero outside the coded range), mask_f / mask_l: which of the lane's samples are coded.
 // Sums of the partitions of every order are kept as a heap (node n has children 2n and 2n + 1); a pass
 // fills three levels from the level below them, so an order-6 search takes two passes.
 template <int NT>
 __device__ inline void rice_search_both(ChooseShared<NT> &S, const EncOptsDev &o, uint32_t bs, uint32_t order0, uint32_t order1,
-                                        bool use1, const uint32_t (&uf)[kRun], const uint32_t (&ul)[kRun])
+                                        bool use1, const uint32_t (&uf)[kRun], const uint32_t (&ul)[kRun], uint32_t mask_f,
+                                        uint32_t mask_l)
 {
     const uint32_t t = threadIdx.x, lane = t & 63;
     const uint32_t lanes = (bs + kRun - 1) / kRun;
@@ -776,12 +852,11 @@ __device__ inline void rice_search_both(ChooseShared<NT> &S, const EncOptsDev &o
         const int po0 = S.po[0], po1 = S.po[1];
         const uint32_t part0 = po0 ? (t * kRun) / (bs >> po0) : 0, part1 = po1 ? (t * kRun) / (bs >> po1) : 0;
         const uint32_t k0 = S.kb[0][(1u << po0) + part0], k1 = use1 ? S.kb[1][(1u << po1) + part1] : 0;
+        // residuals outside the coded range are zero
 #pragma unroll
-        for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = t * kRun + j;
-            if (i >= order0 && i < bs) exact0 += (uf[j] >> k0) + k0 + 1;
-            if (use1 && i >= order1 && i < bs) exact1 += (ul[j] >> k1) + k1 + 1;
-        }
+        for (int j = 0; j < kRun; ++j) { exact0 += uf[j] >> k0; exact1 += ul[j] >> k1; }
+        exact0 += (uint32_t)__popc(mask_f) * (k0 + 1);
+        exact1 = use1 ? exact1 + (uint32_t)__popc(mask_l) * (k1 + 1) : 0;
     }
     exact0 = row_sum32(exact0);
     exact1 = row_sum32(exact1);
@@ -822,22 +897,16 @@ __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ p
     if (t < 32) S.q[t] = lpc_ok ? (int32_t)cs->q[t] : 0;
     {
         int32_t v[kRun];
+        load_block_share<NT>(u.src, bs, u.C, u.B, (int)u.cand, u.stereo, v);
 #pragma unroll
-        for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = t + (uint32_t)j * NT;
-            v[j] = cand_sample(u.src, i < bs ? i : bs - 1, u.C, u.B, (int)u.cand, u.stereo);
-        }
-#pragma unroll
-        for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = t + (uint32_t)j * NT;
-            xs[lds_pos(kFront + i)] = i < bs ? v[j] >> wasted : 0;
-        }
+        for (int j = 0; j < kRun; ++j) xs[lds_pos(kFront + t + (uint32_t)j * NT)] = v[j] >> wasted;
     }
     if (t < lds_lane_base(0)) xs[t] = 0;
     __syncthreads();
 
     // ---- residuals of both predictors
     const uint32_t i0 = t * kRun, lbase = lds_lane_base(t);
+    const uint32_t mask_f = run_mask(i0, (uint32_t)fo, bs), mask_l = lpc_ok ? run_mask(i0, (uint32_t)ord, bs) : 0;
     uint32_t uf[kRun], ul[kRun];
     {
         int32_t w[M + kRun];
@@ -847,37 +916,36 @@ __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ p
             int32_t cq[M];
 #pragma unroll
             for (int q = 0; q < M; ++q) cq[q] = S.q[q];
-            uint32_t bad;
-            if (wide) bad = lpc_residual<M, 2>(w, cq, shift, ul);
-            else if (sb <= 24) bad = lpc_residual<M, 0>(w, cq, shift, ul);
-            else bad = lpc_residual<M, 1>(w, cq, shift, ul);
+            uint32_t high;
+            if (wide) high = lpc_residual<M, 2>(w, cq, shift, ul);
+            else if (sb <= 24) high = lpc_residual<M, 0>(w, cq, shift, ul);
+            else high = lpc_residual<M, 1>(w, cq, shift, ul);
             // only residuals that will be coded count
-            if (bad) {
-                uint32_t coded = 0;
+            if (high && (lpc_residual_bad<M>(w, cq, shift, wide != 0) & mask_l)) atomicOr(&S.lpc_bad, 1u);
+        } else {
 #pragma unroll
-                for (int j = 0; j < kRun; ++j) {
-                    const uint32_t i = i0 + j;
-                    if (i >= (uint32_t)ord && i < bs) coded |= 1u << j;
-                }
-                if (bad & coded) atomicOr(&S.lpc_bad, 1u);
-            }
+            for (int j = 0; j < kRun; ++j) ul[j] = 0;
         }
         fixed_residual<M>(w, fo, uf);
+    }
+    // residuals outside the coded range (warm-up, beyond the block) are cleared: the first and last waves only
+    if (!__all(mask_f == 0xFFFFu && (!lpc_ok || mask_l == 0xFFFFu))) {
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            if (!((mask_f >> j) & 1)) uf[j] = 0;
+            if (!((mask_l >> j) & 1)) ul[j] = 0;
+        }
     }
     {
         uint64_t sf = 0, sl = 0;
 #pragma unroll
-        for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = i0 + j;
-            if (i >= (uint32_t)fo && i < bs) sf += uf[j];
-            if (lpc_ok && i >= (uint32_t)ord && i < bs) sl += ul[j];
-        }
+        for (int j = 0; j < kRun; ++j) { sf += uf[j]; sl += ul[j]; }
         S.psum[0][t] = sf;
         S.psum[1][t] = sl;
     }
     __syncthreads();
     const bool use_lpc = lpc_ok && !S.lpc_bad;
-    rice_search_both<NT>(S, o, bs, (uint32_t)fo, (uint32_t)ord, use_lpc, uf, ul);
+    rice_search_both<NT>(S, o, bs, (uint32_t)fo, (uint32_t)ord, use_lpc, uf, ul, mask_f, mask_l);
     __syncthreads();
 
     // ---- choice and plan
@@ -1120,16 +1188,9 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
     for (uint32_t i = t; i < nwords + 1 && i < buf_words; i += NT) buf[i] = 0;
     {
         int32_t v[kRun];
+        load_block_share<NT>(src, bs, (int)C, B, (int)cand, stereo4, v);
 #pragma unroll
-        for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = t + (uint32_t)j * NT;
-            v[j] = cand_sample(src, i < bs ? i : bs - 1, (int)C, B, (int)cand, stereo4);
-        }
-#pragma unroll
-        for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = t + (uint32_t)j * NT;
-            xs[lds_pos(kFront + i)] = i < bs ? v[j] >> wasted : 0;
-        }
+        for (int j = 0; j < kRun; ++j) xs[lds_pos(kFront + t + (uint32_t)j * NT)] = v[j] >> wasted;
     }
     if (t < lds_lane_base(0)) xs[t] = 0;
     if (t < 32) s_q[t] = type == 3 ? (int32_t)reinterpret_cast<const int16_t *>(plan + kPlanHeadBytes)[t] : 0;
