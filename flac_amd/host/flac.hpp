@@ -256,6 +256,54 @@ public:
         return "";
     }
 
+    // Options of EncodeBatch (flacgpu_encode_options).
+    struct EncodeOptions {
+        uint32_t BlockSize = 4096, MaxLPCOrder = 12, QLPPrecision = 0, MinPartitionOrder = 0, MaxPartitionOrder = 6;
+        int32_t StereoMode = -1;
+        uint32_t ForceLPCOrder = 0;
+        bool MD5OnDevice = true;
+    };
+
+    // Encodes interleaved little-endian PCM (ceil(bps/8) bytes per sample, what DecodeFrames returns) into
+    // complete .flac streams that Metadata::Read accepts.  infos supplies SampleRate, Channels, BitsPerSample
+    // and TotalSamples of every stream.
+    std::string EncodeBatch(const std::vector<std::vector<uint8_t>> &pcm, const std::vector<StreaminfoBlock> &infos,
+                            const EncodeOptions &o, std::vector<std::vector<uint8_t>> &files)
+    {
+        if (!h_) return "decoder is not open";
+        const size_t n = pcm.size();
+        if (n == 0 || n != infos.size()) return "EncodeBatch: streams and STREAMINFO blocks differ in number";
+        flacgpu_encode_options opts = {};
+        opts.struct_size = sizeof opts; opts.blocksize = o.BlockSize; opts.max_lpc_order = o.MaxLPCOrder;
+        opts.qlp_precision = o.QLPPrecision; opts.min_partition_order = o.MinPartitionOrder;
+        opts.max_partition_order = o.MaxPartitionOrder; opts.stereo_mode = o.StereoMode;
+        opts.force_lpc_order = o.ForceLPCOrder; opts.flags = o.MD5OnDevice ? FLACGPU_ENC_MD5 : 0;
+        std::vector<flacgpu_pcm_stream> streams(n);
+        std::vector<const uint8_t *> in(n);
+        std::vector<uint8_t *> out(n);
+        std::vector<uint64_t> caps(n);
+        std::vector<flacgpu_encode_result> res(n);
+        files.assign(n, {});
+        for (size_t i = 0; i < n; ++i) {
+            const StreaminfoBlock &s = infos[i];
+            flacgpu_pcm_stream &ps = streams[i];
+            ps = flacgpu_pcm_stream{};
+            ps.total_samples = s.TotalSamples; ps.sample_rate = s.SampleRate;
+            ps.channels = s.Channels; ps.bits_per_sample = s.BitsPerSample;
+            if (pcm[i].size() != s.TotalSamples * s.Channels * ((s.BitsPerSample + 7u) / 8u)) return "EncodeBatch: PCM size does not match TotalSamples";
+            caps[i] = flacgpu_encode_bound(s.TotalSamples, s.Channels, s.BitsPerSample, o.BlockSize);
+            files[i].resize((size_t)caps[i]);
+            in[i] = pcm[i].data(); out[i] = files[i].data();
+        }
+        if (int rc = flacgpu_encode_batch(h_, in.data(), streams.data(), (uint32_t)n, &opts, out.data(), caps.data(), res.data()))
+            return std::string("encode: ") + flacgpu_status_string(rc) + ": " + flacgpu_last_error(h_);
+        for (size_t i = 0; i < n; ++i) {
+            if (res[i].status) return std::string("encode: stream ") + std::to_string(i) + ": " + flacgpu_status_string(res[i].status);
+            files[i].resize((size_t)res[i].out_length);
+        }
+        return "";
+    }
+
 private:
     flacgpu_handle *h_ = nullptr;
 };

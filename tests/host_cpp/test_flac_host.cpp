@@ -122,6 +122,23 @@ static void stereo(const std::string &dir, bool gpu)
         CHECK(dec.DecodeFrames(got, f, pcm, r).empty());
         CHECK(r.Frames == 36 && r.FramesOK == 36 && r.Samples == 162496);
         CHECK(md5hex(pcm) == si.MD5Signature);
+        // write side: the PCM just decoded goes through EncodeBatch, the result through Read and DecodeFrames again
+        std::vector<std::vector<uint8_t>> files;
+        flac::Decoder::EncodeOptions eo;
+        eo.BlockSize = 4608;
+        CHECK(dec.EncodeBatch({pcm}, {si}, eo, files).empty());
+        CHECK(files.size() == 1 && files[0].size() > 42);
+        std::istringstream g(std::string(files[0].begin(), files[0].end()));
+        flac::Metadata again;
+        CHECK(again.Read(g).empty());
+        CHECK(again.FirstFrameOffset == 42 && again.Streaminfo.IsPopulated);
+        const flac::StreaminfoBlock &t = again.Streaminfo.Data;
+        CHECK(t.MinBlockSize == 4608 && t.MaxBlockSize == 4608 && t.SampleRate == si.SampleRate && t.Channels == si.Channels);
+        CHECK(t.BitsPerSample == si.BitsPerSample && t.TotalSamples == si.TotalSamples && t.MD5Signature == si.MD5Signature);
+        std::vector<uint8_t> pcm2;
+        flac::StreamResult r2;
+        CHECK(dec.DecodeFrames(again, g, pcm2, r2).empty());
+        CHECK(r2.Frames == 36 && r2.FramesOK == 36 && pcm2 == pcm);
     }
 }
 
