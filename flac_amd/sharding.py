@@ -17,6 +17,27 @@ def shard_indices(n_items: int, rank: int, world: int) -> range:
     return range(rank, n_items, world)
 
 
+def range_shards(seekpoints, audio_len: int, parts: int):
+    """Cuts ONE stream into `parts` contiguous frame ranges at seek points (SeekpointBlock.Offset, bytes from
+    frame 0, flacmeta.go:256-260: every seek point is the first byte of a frame), as evenly by bytes as the
+    points allow.  Returns [(offset, length)] covering [0, audio_len) in order; ranges may be fewer than
+    `parts` when the table is short.  Placeholder points (sample number 2^64 - 1) are ignored.  Every frame
+    carries its own frame or sample number, so each range decodes on its own, on any GPU, into the same
+    output region as the others."""
+    if parts < 1:
+        raise ValueError("parts must be at least 1")
+    offs = sorted({int(p.offset) for p in seekpoints
+                   if int(p.sample_number) != 0xFFFFFFFFFFFFFFFF and 0 < int(p.offset) < audio_len})
+    cuts = [0]
+    for k in range(1, parts):
+        want = audio_len * k // parts
+        best = min(offs, key=lambda o: abs(o - want), default=None)
+        if best is not None and best > cuts[-1]:
+            cuts.append(best)
+    cuts.append(audio_len)
+    return [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
 def result_rows(indices, results, digests=None) -> np.ndarray:
     """One int64 row per stream: global index, the counters of flacgpu_stream_result, and (optionally)
     a 128-bit digest of its PCM split in two words (e.g. the MD5 the caller computed)."""

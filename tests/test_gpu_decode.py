@@ -129,3 +129,31 @@ def test_device_md5_matches_streaminfo(decoder, testdata):
     got = decoder.md5_batch_device(d, cat.size, o2, [p.size for p in pcms])
     assert [g.hex() for g in got] == [si.md5_signature for si in infos]
     assert got[0].hex() == "e5ccc967ced6c111530e5c79e33c969e" and got[1].hex() == "6291dbd8dcb7dc480132e4c4ba154a17"
+
+
+def test_frame_range_shards_of_one_stream(decoder):
+    """One long stream cut at SEEKTABLE offsets (flacmeta.go:612-641) into frame ranges that decode as
+    independent batch entries into the same output region: the way a single stream is spread over the
+    GPUs of a node.  Fixed and variable block size."""
+    import torch
+    from flac_amd import sharding
+    for kw, ch, bps in ((dict(), 2, 16), (dict(variable_blocksize=1, var_sizes=[1024, 4096, 576, 2000]), 2, 16),
+                        (dict(), 8, 24)):
+        x = synth.pcm(91, 4096 * 23 + 321, ch, bps, 48000, 4096)
+        f, ff = synth.encode(x, bps, 48000, synth.options(4096, 12, seek_every_frames=3, **kw))
+        f = bytes(f)
+        md = flac_amd.parse_metadata(f)
+        seek = [b for b in md.blocks[: md.n_blocks] if b.type == 4][0]
+        pts = flac_amd.parse_seektable(f[seek.payload_offset: seek.payload_offset + seek.length])
+        si, audio = split_file(f)
+        shards = sharding.range_shards(pts, len(audio), 5)
+        assert len(shards) == 5
+        want, ost = oracle_decode(si, audio)
+        d_in = torch.frombuffer(bytearray(audio) + bytearray(64), dtype=torch.uint8).cuda()
+        d_out = torch.full((si.pcm_bytes + 64,), 0xAA, dtype=torch.uint8, device="cuda")
+        streams = decoder.make_streams([(o, n, 0, si.pcm_bytes, si) for o, n in shards])
+        res = decoder.decode_batch_device(d_in, len(audio), d_out, si.pcm_bytes + 64, streams)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy()[: si.pcm_bytes], want)
+        assert sum(r.frames_ok for r in res) == sum(r.frames for r in res) == ost.frames_ok
+        assert sum(r.samples for r in res) == si.total_samples

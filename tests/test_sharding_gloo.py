@@ -39,3 +39,18 @@ def test_two_ranks_equal_one(tmp_path):
     t1, t2 = np.array(one["table"]), np.array(two["table"])
     assert np.array_equal(t1, t2)
     assert (t1[:, 2] == t1[:, 1]).all() and (t1[:, 1] > 0).all()   # every frame of every stream decoded
+
+
+def test_range_shards_cover_the_stream():
+    class P:
+        def __init__(self, s, o):
+            self.sample_number, self.offset = s, o
+    pts = [P(i * 4096, i * 1000) for i in range(1, 40)] + [P(0xFFFFFFFFFFFFFFFF, 0)]
+    for parts in (1, 2, 3, 8, 100):
+        sh = sharding.range_shards(pts, 40000, parts)
+        assert sh[0][0] == 0 and sum(n for _, n in sh) == 40000
+        assert all(a + n == b for (a, n), (b, _) in zip(sh[:-1], sh[1:]))
+        assert all(a % 1000 == 0 for a, _ in sh)
+        assert len(sh) <= parts
+    assert sharding.range_shards([], 500, 4) == [(0, 500)]
+    assert len(sharding.range_shards(pts, 40000, 8)) == 8
