@@ -108,13 +108,13 @@ class EncodeOptions(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("blocksize", ctypes.c_uint32), ("max_lpc_order", ctypes.c_uint32),
                 ("qlp_precision", ctypes.c_uint32), ("min_partition_order", ctypes.c_uint32),
                 ("max_partition_order", ctypes.c_uint32), ("stereo_mode", ctypes.c_int32),
-                ("force_lpc_order", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("force_lpc_order", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("seektable_interval", ctypes.c_uint32)]
 
 
 def encode_options(blocksize=4096, max_lpc_order=12, qlp_precision=0, min_partition_order=0, max_partition_order=6,
-                   stereo_mode=-1, force_lpc_order=0, flags=0) -> EncodeOptions:
+                   stereo_mode=-1, force_lpc_order=0, flags=0, seektable_interval=0) -> EncodeOptions:
     return EncodeOptions(ctypes.sizeof(EncodeOptions), blocksize, max_lpc_order, qlp_precision, min_partition_order,
-                         max_partition_order, stereo_mode, force_lpc_order, flags, 0)
+                         max_partition_order, stereo_mode, force_lpc_order, flags, seektable_interval)
 
 
 class PcmStream(ctypes.Structure):
@@ -145,7 +145,7 @@ EXPORTS = [
     "flacgpu_status_string", "flacgpu_create", "flacgpu_destroy", "flacgpu_last_error", "flacgpu_scan_frames",
     "flacgpu_decode_batch_device", "flacgpu_decode_batch", "flacgpu_get_timing",
     "flacgpu_encode_bound", "flacgpu_encode_batch_device", "flacgpu_encode_batch", "flacgpu_get_encode_timing",
-    "flacgpu_md5_batch_device",
+    "flacgpu_md5_batch_device", "flacgpu_seektable_bytes",
 ]
 
 _lib = None
@@ -195,6 +195,8 @@ def lib():
         L.flacgpu_get_timing.argtypes = [vp, ctypes.POINTER(Timing)]
         L.flacgpu_encode_bound.restype = u64
         L.flacgpu_encode_bound.argtypes = [u64, u32, u32, u32]
+        L.flacgpu_seektable_bytes.restype = u64
+        L.flacgpu_seektable_bytes.argtypes = [u64, u32, u32]
         L.flacgpu_encode_batch_device.argtypes = [vp, vp, u64, vp, u64, ctypes.POINTER(PcmStream), u32,
                                                   ctypes.POINTER(EncodeOptions), ctypes.POINTER(EncodeResult), vp]
         L.flacgpu_encode_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(PcmStream), u32,
@@ -363,7 +365,7 @@ class Decoder:
         shapes: per stream (total_samples, sample_rate, channels, bps[, md5])."""
         n = len(pcm_list)
         arrs = [np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8)) for a in pcm_list]
-        caps = [encode_bound(sh[0], sh[2], sh[3], opts.blocksize) for sh in shapes]
+        caps = [encode_bound(sh[0], sh[2], sh[3], opts.blocksize, opts.seektable_interval) for sh in shapes]
         outs = [np.zeros(c, dtype=np.uint8) for c in caps]
         streams = self.make_pcm_streams((0, sh[0], 0, 0, sh[1], sh[2], sh[3], sh[4] if len(sh) > 4 else None)
                                         for sh in shapes)
@@ -395,9 +397,10 @@ class Decoder:
 Engine = Decoder
 
 
-def encode_bound(total_samples, channels, bps, blocksize) -> int:
-    """flacgpu_encode_bound: a capacity that always fits one encoded stream."""
-    return int(lib().flacgpu_encode_bound(int(total_samples), int(channels), int(bps), int(blocksize)))
+def encode_bound(total_samples, channels, bps, blocksize, seektable_interval=0) -> int:
+    """flacgpu_encode_bound (+ flacgpu_seektable_bytes): a capacity that always fits one encoded stream."""
+    return int(lib().flacgpu_encode_bound(int(total_samples), int(channels), int(bps), int(blocksize))) + \
+        int(lib().flacgpu_seektable_bytes(int(total_samples), int(blocksize), int(seektable_interval)))
 
 
 def decode_file(path_or_bytes, decoder: Decoder = None):

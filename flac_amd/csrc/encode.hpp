@@ -58,7 +58,8 @@ struct EncStreamDev {
     int32_t  status;          // result
     uint8_t  channels, bps, bytes_ps, ncand;
     uint8_t  md5[16];
-    uint32_t pad[3];
+    uint32_t meta_len;        // bytes in front of frame 0: 42, plus 4 + 18 per seek point
+    uint32_t pad[2];
 };
 
 struct EncOptsDev {
@@ -66,6 +67,7 @@ struct EncOptsDev {
     int32_t  stereo_mode;
     uint32_t force_lpc_order;
     uint32_t plan_stride;     // bytes per plan
+    uint32_t seek_every;      // frames per seek point, 0 = no SEEKTABLE block
     uint32_t total_units, total_pack, total_frames;
 };
 
@@ -1083,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
         uint32_t total;
         const uint32_t excl = block_excl_scan<256>(bytes, s_w, total);
         if (f < nf) {
-            fr.out_off = st.out_off + 42 + s_carry + excl;
+            fr.out_off = st.out_off + st.meta_len + s_carry + excl;
             frames[st.frame_begin + f] = fr;
         }
         __syncthreads();
@@ -1093,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
     mn = wave_min32(mn); mx = wave_max32(mx);
     if (lane == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
     __syncthreads();
-    const uint64_t out_len = 42 + s_carry;
+    const uint64_t out_len = st.meta_len + s_carry;
     const bool fits = out_len <= st.out_cap;
     if (t == 0) {
         st.out_len = out_len;
@@ -1104,7 +1106,12 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
             // marker, block header (flacmeta.go:519-551) and STREAMINFO (flacmeta.go:644-717)
             uint8_t *p = out + st.out_off;
             p[0] = 'f'; p[1] = 'L'; p[2] = 'a'; p[3] = 'C';
-            p[4] = 0x80; p[5] = 0; p[6] = 0; p[7] = 34;
+            p[4] = o.seek_every ? 0x00 : 0x80; p[5] = 0; p[6] = 0; p[7] = 34;
+            if (o.seek_every) {
+                // SEEKTABLE block header (type 3, last), flacmeta.go:519-551; its points are written below
+                const uint32_t len = st.meta_len - 46;
+                p[42] = 0x83; p[43] = (uint8_t)(len >> 16); p[44] = (uint8_t)(len >> 8); p[45] = (uint8_t)len;
+            }
             uint8_t *s = p + 8;
             const uint32_t Bk = o.blocksize, mnf = st.min_fs, mxf = st.max_fs;
             s[0] = (uint8_t)(Bk >> 8); s[1] = (uint8_t)Bk; s[2] = (uint8_t)(Bk >> 8); s[3] = (uint8_t)Bk;
@@ -1134,6 +1141,13 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
         for (uint32_t i = 0; i < hl; ++i) out[lo + i] = hb[i];
         crc_off[g] = lo;
         crc_len[g] = fr.bytes - 2;
+        if (o.seek_every && f % o.seek_every == 0) {
+            // SeekpointBlock, flacmeta.go:256-260 / :612-641: sample number, byte offset from frame 0, frame samples
+            uint8_t *sp = out + st.out_off + 46 + (uint64_t)(f / o.seek_every) * 18;
+            const uint64_t sample = (uint64_t)f * o.blocksize, off = lo - (st.out_off + st.meta_len);
+            for (int k = 0; k < 8; ++k) { sp[k] = (uint8_t)(sample >> (56 - 8 * k)); sp[8 + k] = (uint8_t)(off >> (56 - 8 * k)); }
+            sp[16] = (uint8_t)(fr.bs >> 8); sp[17] = (uint8_t)fr.bs;
+        }
     }
 }
 

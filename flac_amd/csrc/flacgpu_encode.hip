@@ -113,6 +113,13 @@ uint64_t flacgpu_encode_bound(uint64_t total_samples, uint32_t channels, uint32_
     return 42 + frames * per_frame;
 }
 
+uint64_t flacgpu_seektable_bytes(uint64_t total_samples, uint32_t blocksize, uint32_t seektable_interval)
+{
+    if (!blocksize || !seektable_interval) return 0;
+    const uint64_t frames = (total_samples + blocksize - 1) / blocksize;
+    return 4 + 18 * ((frames + seektable_interval - 1) / seektable_interval);
+}
+
 int flacgpu_get_encode_timing(const flacgpu_handle *h, flacgpu_encode_timing *out)
 {
     if (!h || !out) return FLACGPU_ERR_ARG;
@@ -179,6 +186,8 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
         d.ncand = s.channels == 2 ? 4 : s.channels;
         d.win_off = window_of(B);
         d.win_off_tail = d.tail_bs ? window_of(d.tail_bs) : d.win_off;
+        d.meta_len = 42 + (uint32_t)flacgpu_seektable_bytes(s.total_samples, B, opts->seektable_interval);
+        if (d.meta_len - 46 >= (1u << 24) && opts->seektable_interval) return fail(h, FLACGPU_ERR_ARG, "seek table longer than a metadata block allows");
         std::memcpy(d.md5, s.md5, 16);
         frames += nf; units += nf * d.ncand; pack_units += nf * d.channels; in_total += in_len;
         max_bps = std::max<uint32_t>(max_bps, s.bits_per_sample);
@@ -190,6 +199,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     o.blocksize = B; o.max_lpc_order = opts->max_lpc_order; o.qlp_precision = opts->qlp_precision;
     o.min_po = opts->min_partition_order; o.max_po = opts->max_partition_order; o.stereo_mode = opts->stereo_mode;
     o.force_lpc_order = opts->force_lpc_order;
+    o.seek_every = opts->seektable_interval;
     o.plan_stride = (uint32_t)((kPlanHeadBytes + kPlanCoefBytes + (1u << opts->max_partition_order) + 15) & ~15u);
     o.total_units = (uint32_t)units; o.total_pack = (uint32_t)pack_units; o.total_frames = (uint32_t)frames;
 

@@ -247,7 +247,8 @@ typedef struct flacgpu_encode_options {
     int32_t  stereo_mode;          /* -1 cheapest per frame, 0 left/right, 1 left/side, 2 side/right, 3 mid/side */
     uint32_t force_lpc_order;      /* 0 = estimate the order per subframe; else exactly this order */
     uint32_t flags;                /* FLACGPU_ENC_*                                                */
-    uint32_t reserved;
+    uint32_t seektable_interval;   /* a seek point every this many frames (SEEKTABLE block after STREAMINFO,
+                                      SeekpointBlock flacmeta.go:256-260); 0 = no seek table       */
 } flacgpu_encode_options;
 
 #define FLACGPU_ENC_MD5 1u   /* hash the PCM on the device for STREAMINFO (one lane per stream) */
@@ -269,7 +270,7 @@ typedef struct flacgpu_pcm_stream {
 } flacgpu_pcm_stream;
 
 typedef struct flacgpu_encode_result {
-    uint64_t out_length;       /* bytes of the .flac stream (42 + frames), also when it did not fit */
+    uint64_t out_length;       /* bytes of the .flac stream (metadata + frames), also when it did not fit */
     uint64_t frames;
     uint32_t min_framesize;
     uint32_t max_framesize;
@@ -293,8 +294,12 @@ typedef struct flacgpu_encode_timing {
     uint64_t out_bytes;  /* .flac bytes produced                                      */
 } flacgpu_encode_timing;
 
-/* Largest possible size of one encoded stream: a capacity that always fits. */
+/* Largest possible size of one encoded stream without a seek table: a capacity
+ * that always fits.  With seektable_interval set, add flacgpu_seektable_bytes. */
 uint64_t flacgpu_encode_bound(uint64_t total_samples, uint32_t channels, uint32_t bits_per_sample, uint32_t blocksize);
+
+/* Bytes of the SEEKTABLE block (header + 18 per point) the encoder writes. */
+uint64_t flacgpu_seektable_bytes(uint64_t total_samples, uint32_t blocksize, uint32_t seektable_interval);
 
 /* Encodes a device-resident batch into complete .flac streams (marker,
  * STREAMINFO, fixed-blocksize frames).  d_pcm / d_out: device pointers, 16-byte

@@ -71,6 +71,7 @@ class EncOpts(ctypes.Structure):
         ("stereo_mode", ctypes.c_int32),
         ("force_lpc_order", ctypes.c_uint32),
         ("flags", ctypes.c_uint32),
+        ("seektable_interval", ctypes.c_uint32),
     ]
 
 
@@ -183,9 +184,9 @@ def decode_batch(data: np.ndarray, offs, lens, infos, pcm: np.ndarray, pcm_offs,
 
 
 def enc_options(blocksize=4096, max_lpc_order=12, qlp_precision=0, min_partition_order=0, max_partition_order=6,
-                stereo_mode=-1, force_lpc_order=0, flags=0) -> EncOpts:
+                stereo_mode=-1, force_lpc_order=0, flags=0, seektable_interval=0) -> EncOpts:
     return EncOpts(blocksize, max_lpc_order, qlp_precision, min_partition_order, max_partition_order, stereo_mode,
-                   force_lpc_order, flags)
+                   force_lpc_order, flags, seektable_interval)
 
 
 def encode_window(bs: int) -> np.ndarray:
@@ -203,7 +204,10 @@ def encode_stream(pcm, total_samples, channels, bps, sample_rate, opts: EncOpts,
     frames, min_framesize, max_framesize)."""
     a = np.ascontiguousarray(np.frombuffer(pcm, dtype=np.uint8))
     assert a.size == total_samples * channels * ((bps + 7) // 8)
+    frames = (total_samples + opts.blocksize - 1) // opts.blocksize
     cap = encode_bound(total_samples, channels, bps, opts.blocksize)
+    if opts.seektable_interval:
+        cap += 4 + 18 * ((frames + opts.seektable_interval - 1) // opts.seektable_interval)
     out = np.zeros(cap, dtype=np.uint8)
     n, nf, mn, mx = ctypes.c_size_t(), ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32()
     m = (ctypes.c_uint8 * 16)(*md5) if md5 is not None else None

@@ -470,7 +470,11 @@ int orc_encode_stream(const uint8_t *pcm, uint64_t total_samples, int channels, 
     float *win = (float *)malloc(B * sizeof(float));
     uint32_t win_bs = 0;
 
-    size_t pos = 42;
+    const uint64_t total_frames = (total_samples + B - 1) / B;
+    const uint64_t npoints = o->seektable_interval ? (total_frames + o->seektable_interval - 1) / o->seektable_interval : 0;
+    const size_t meta_len = 42 + (o->seektable_interval ? 4 + 18 * (size_t)npoints : 0);
+    if (cap < meta_len) return ORC_ERR_CAPACITY;
+    size_t pos = meta_len;
     uint32_t min_fs = 0xFFFFFF, max_fs = 0;
     uint64_t frame_no = 0;
     int rc = ORC_OK;
@@ -511,6 +515,13 @@ int orc_encode_stream(const uint8_t *pcm, uint64_t total_samples, int channels, 
 
         size_t fstart = pos;
         if (cap - pos < 32) { rc = ORC_ERR_CAPACITY; break; }
+        if (o->seektable_interval && frame_no % o->seektable_interval == 0) {
+            /* SeekpointBlock, flacmeta.go:256-260: sample number, offset from frame 0, frame samples */
+            uint8_t *sp = out + 46 + (size_t)(frame_no / o->seektable_interval) * 18;
+            uint64_t off = fstart - meta_len;
+            for (int k = 0; k < 8; k++) { sp[k] = (uint8_t)(done >> (56 - 8 * k)); sp[8 + k] = (uint8_t)(off >> (56 - 8 * k)); }
+            sp[16] = (uint8_t)(bs >> 8); sp[17] = (uint8_t)bs;
+        }
         uint8_t *hp = out + pos;
         int hn = 0;
         hp[hn++] = 0xFF;
@@ -549,7 +560,11 @@ int orc_encode_stream(const uint8_t *pcm, uint64_t total_samples, int channels, 
     /* marker, block header, STREAMINFO (flacmeta.go:754-761, :519-551, :644-717) */
     if (min_fs == 0xFFFFFF) min_fs = 0;
     memcpy(out, "fLaC", 4);
-    out[4] = 0x80; out[5] = 0; out[6] = 0; out[7] = 34;
+    out[4] = o->seektable_interval ? 0x00 : 0x80; out[5] = 0; out[6] = 0; out[7] = 34;
+    if (o->seektable_interval) {
+        uint32_t len = (uint32_t)(meta_len - 46);
+        out[42] = 0x83; out[43] = (uint8_t)(len >> 16); out[44] = (uint8_t)(len >> 8); out[45] = (uint8_t)len;
+    }
     uint8_t *s = out + 8;
     s[0] = (uint8_t)(B >> 8); s[1] = (uint8_t)B; s[2] = (uint8_t)(B >> 8); s[3] = (uint8_t)B;
     s[4] = (uint8_t)(min_fs >> 16); s[5] = (uint8_t)(min_fs >> 8); s[6] = (uint8_t)min_fs;

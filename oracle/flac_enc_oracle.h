@@ -30,6 +30,7 @@ typedef struct {
     int32_t  stereo_mode;
     uint32_t force_lpc_order;
     uint32_t flags;
+    uint32_t seektable_interval;
 } orc_enc_opts;
 
 /* Tukey(0.5) analysis window of a block of bs samples, as single-precision values. */

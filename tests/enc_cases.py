@@ -18,6 +18,8 @@ ENC_GROUPS = [
     dict(name="odd-bs-forced-stereo", opts=dict(blocksize=1000, max_lpc_order=8, max_partition_order=6, stereo_mode=3,
                                                  qlp_precision=9),
          streams=[(2, 16, 44100, 7777), (2, 24, 44100, 3000)]),
+    dict(name="seektable", opts=dict(blocksize=1024, max_lpc_order=8, max_partition_order=4, seektable_interval=3),
+         streams=[(2, 16, 44100, 1024 * 10 + 5), (1, 24, 48000, 1024 * 3), (2, 16, 44100, 700), (2, 16, 8000, 1024 * 7)]),
     dict(name="left-side", opts=dict(blocksize=576, max_lpc_order=6, max_partition_order=3, stereo_mode=1),
          streams=[(2, 16, 22050, 4000)]),
     dict(name="side-right", opts=dict(blocksize=2304, max_lpc_order=12, max_partition_order=5, stereo_mode=2),

@@ -15,7 +15,13 @@ import pydecoder
 def _check_file(f, packed, shape, opts):
     n, rate, ch, bps = shape
     md = flac_amd.parse_metadata(bytes(f))
-    assert md.first_frame_offset == 42 and md.n_blocks == 1 and md.blocks[0].last == 1
+    nframes = (n + opts.blocksize - 1) // opts.blocksize
+    if opts.seektable_interval:
+        npts = (nframes + opts.seektable_interval - 1) // opts.seektable_interval
+        assert md.first_frame_offset == 46 + 18 * npts and md.n_blocks == 2
+        assert (md.blocks[0].last, md.blocks[1].last, md.blocks[1].type, md.blocks[1].length) == (0, 1, 4, 18 * npts)
+    else:
+        assert md.first_frame_offset == 42 and md.n_blocks == 1 and md.blocks[0].last == 1
     si = md.streaminfo
     assert (si.min_blocksize, si.max_blocksize) == (opts.blocksize, opts.blocksize)
     assert (si.sample_rate, si.channels, si.bits_per_sample, si.total_samples) == (rate, ch, bps, n)
@@ -28,7 +34,14 @@ def _check_file(f, packed, shape, opts):
     assert len(frames) == (n + opts.blocksize - 1) // opts.blocksize == st.frames_ok
     if sizes:
         assert (min(sizes), max(sizes)) == (si.min_framesize, si.max_framesize)
-    assert len(f) == 42 + sum(sizes)
+    assert len(f) == md.first_frame_offset + sum(sizes)
+    if opts.seektable_interval:
+        # every seek point names a frame: its first sample, its offset from frame 0 and its length in samples
+        pts = flac_amd.parse_seektable(bytes(f[46: md.first_frame_offset]))
+        by_sample = {fr.first_sample: fr for fr in frames}
+        assert [p.sample_number for p in pts] == [k * opts.seektable_interval * opts.blocksize for k in range(len(pts))]
+        for p in pts:
+            assert (by_sample[p.sample_number].offset, by_sample[p.sample_number].blocksize) == (p.offset, p.frame_samples)
 
 
 @pytest.mark.parametrize("group", ENC_GROUPS, ids=[g["name"] for g in ENC_GROUPS])

@@ -103,7 +103,7 @@ def gpu_encode_group(engine, packed, shapes, opts, cap_scale=1.0, md5s=None):
     pcm_bytes = pos + 256
     pos = 0
     for (n, rate, ch, bps) in shapes:
-        cap = int(flac_amd.encode_bound(n, ch, bps, opts.blocksize) * cap_scale)
+        cap = int(flac_amd.encode_bound(n, ch, bps, opts.blocksize, opts.seektable_interval) * cap_scale)
         caps.append(cap)
         out_offs.append(pos)
         pos += (cap + 255) // 256 * 256
