@@ -102,7 +102,9 @@ struct FrameRec {             // 64 bytes
 template <int CTRL>
 __device__ inline uint32_t dpp_move(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    // every lane has a source lane for these patterns, so the previous value of the destination is dead:
+    // bound_ctrl with a constant spares the copy the compiler would make to preserve it
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ inline uint64_t dpp_move64(uint64_t v)
@@ -557,22 +559,56 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
         // first lane (samples 0..3 do not count) and the lanes at the end of the block need the range test.
         uint64_t e64[5] = {0, 0, 0, 0, 0};
         const uint32_t counted = run_mask(i0, 4, bs);
-        const bool all_counted = __all(counted == 0xFFFFu);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            uint32_t e32[5] = {0, 0, 0, 0, 0};
-#pragma unroll
-            for (int jj = 0; jj < kRun / 2; ++jj) {
-                const int j = half * (kRun / 2) + jj;
-                const int32_t a = w[4 + j], b = w[3 + j], c = w[2 + j], d = w[1 + j], e = w[j];
-                const int32_t d1 = a - b, d2 = a - 2 * b + c, d3 = a - 3 * b + 3 * c - d, d4 = a - 4 * b + 6 * c - 4 * d + e;
-                uint32_t a0 = (uint32_t)(a < 0 ? -a : a), a1 = (uint32_t)(d1 < 0 ? -d1 : d1), a2 = (uint32_t)(d2 < 0 ? -d2 : d2),
-                         a3 = (uint32_t)(d3 < 0 ? -d3 : d3), a4 = (uint32_t)(d4 < 0 ? -d4 : d4);
-                if (!all_counted && !((counted >> j) & 1)) { a0 = 0; a1 = 0; a2 = 0; a3 = 0; a4 = 0; }
-                e32[0] += a0; e32[1] += a1; e32[2] += a2; e32[3] += a3; e32[4] += a4;
+        if (__all(counted == 0xFFFFu)) {
+            // Differences of order k are differences of the differences of order k-1.  Everything is kept
+            // with 2^31 added (top bit flipped), which turns signed order into unsigned order, so that
+            // |d| = |D(i) - D(i-1)| is one unsigned sum-of-absolute-differences instruction that also adds
+            // to the running sum.
+            constexpr uint32_t Z = 0x80000000u;
+            uint32_t p0 = (uint32_t)w[3] ^ Z, p1, p2, p3;   // D0..D3 of the sample before the run
+            {
+                const uint32_t x0 = (uint32_t)w[0] ^ Z, x1 = (uint32_t)w[1] ^ Z, x2 = (uint32_t)w[2] ^ Z;
+                const uint32_t a1 = (x1 - x0) ^ Z, a2 = (x2 - x1) ^ Z, a3 = (p0 - x2) ^ Z;   // first differences
+                const uint32_t b2 = (a2 - a1) ^ Z, b3 = (a3 - a2) ^ Z;                       // second
+                p1 = a3; p2 = b3; p3 = (b3 - b2) ^ Z;
             }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) e64[k] += e32[k];
+            for (int half = 0; half < 2; ++half) {
+                uint32_t e32[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+                for (int jj = 0; jj < kRun / 2; ++jj) {
+                    const int j = half * (kRun / 2) + jj;
+                    const uint32_t c0 = (uint32_t)w[4 + j] ^ Z;
+                    e32[0] = __usad(c0, Z, e32[0]);
+                    e32[1] = __usad(c0, p0, e32[1]);
+                    const uint32_t c1 = (c0 - p0) ^ Z;
+                    e32[2] = __usad(c1, p1, e32[2]);
+                    const uint32_t c2 = (c1 - p1) ^ Z;
+                    e32[3] = __usad(c2, p2, e32[3]);
+                    const uint32_t c3 = (c2 - p2) ^ Z;
+                    e32[4] = __usad(c3, p3, e32[4]);
+                    p0 = c0; p1 = c1; p2 = c2; p3 = c3;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) e64[k] += e32[k];
+            }
+        } else {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint32_t e32[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+                for (int jj = 0; jj < kRun / 2; ++jj) {
+                    const int j = half * (kRun / 2) + jj;
+                    const int32_t a = w[4 + j], b = w[3 + j], c = w[2 + j], d = w[1 + j], e = w[j];
+                    const int32_t d1 = a - b, d2 = a - 2 * b + c, d3 = a - 3 * b + 3 * c - d, d4 = a - 4 * b + 6 * c - 4 * d + e;
+                    if ((counted >> j) & 1) {
+                        e32[0] += (uint32_t)(a < 0 ? -a : a); e32[1] += (uint32_t)(d1 < 0 ? -d1 : d1); e32[2] += (uint32_t)(d2 < 0 ? -d2 : d2);
+                        e32[3] += (uint32_t)(d3 < 0 ? -d3 : d3); e32[4] += (uint32_t)(d4 < 0 ? -d4 : d4);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) e64[k] += e32[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
