@@ -75,6 +75,28 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
                     f"{res[i].min_framesize}/{res[i].max_framesize} head {f[:80].hex()}")
                 raise
             assert hashlib.md5(pcm.tobytes()).hexdigest() == infos[i % unique].md5_signature, f"encode round trip, stream {i}"
+    # CPU baseline of the encode leg: the encoder oracle (a scalar C port of the same algorithm) on a few files
+    cpu_enc = None
+    if rank == 0 and args.cpu_files > 0:
+        import oracle
+        from concurrent.futures import ThreadPoolExecutor
+        ncpu = min(threads, unique, nfiles)
+        pcms = [d_pcm[i * pcm_stride: i * pcm_stride + pcm_bytes_per_file].cpu().numpy().tobytes() for i in range(ncpu)]
+        oo = oracle.enc_options(blocksize=blocksize, max_lpc_order=args.lpc_order, max_partition_order=opts.max_partition_order,
+                                min_partition_order=opts.min_partition_order, force_lpc_order=args.force_lpc_order)
+        cpu_s, passes = 0.0, 0
+        with ThreadPoolExecutor(max_workers=threads) as ex:   # ctypes releases the GIL inside the C call
+            while cpu_s < 0.5 * args.cpu_seconds and passes < 64:
+                t0 = time.perf_counter()
+                outs = list(ex.map(lambda p: oracle.encode_stream(p, nsamples, channels, bps, rate, oo, md5=bytes(16))[0], pcms))
+                cpu_s += time.perf_counter() - t0
+                passes += 1
+        for i, o in enumerate(outs):     # the GPU's bytes equal the oracle's (MD5 field aside: the oracle was given zeros)
+            g = d_enc[i * cap: i * cap + int(res[i].out_length)].cpu().numpy()
+            assert g.size == o.size and np.array_equal(g[42:], o[42:]) and np.array_equal(g[:26], o[:26]), f"encode parity, stream {i}"
+        cpu_enc = {"value": passes * ncpu * nsamples * channels / cpu_s, "unit": "samples/s", "cores": min(threads, ncpu), "kind": "port",
+                   "sample": f"{ncpu} files of the workload ({ncpu * pcm_bytes_per_file / 1e6:.0f} MB PCM) encoded {passes} times, "
+                             f"oracle/flac_enc_oracle.c, {min(threads, ncpu)} threads, {cpu_s:.2f} s"}
     kernel_ms = {k: 0.0 for k in ("stats_ms", "design_ms", "choose_ms", "layout_ms", "pack_ms", "crc_ms", "total_ms")}
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -94,7 +116,7 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
     return {"metric": "encoded PCM samples/sec (per GPU)", "value": values * args.encode_steps / elapsed, "unit": "samples/s",
             "steps": args.encode_steps, "ms_per_step": elapsed / args.encode_steps * 1e3, "flac_GB": flac_total / 1e9,
             "ratio": flac_total / pcm_total, "algorithmic_GB_per_s": alg * args.encode_steps / elapsed / 1e9,
-            "kernel_ms": kernel_ms,
+            "kernel_ms": kernel_ms, "cpu_baseline": cpu_enc,
             "roofline": {"bound": "hbm", "kernel": "k_enc_" + dom[:-3], "achieved": alg / a_s / 1e9 if a_s > 0 else 0.0, "peak": 8000.0,
                          "unit": "GB/s", "frac": alg / a_s / 1e9 / 8000.0 if a_s > 0 else 0.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kernel_ms[dom]}}
