@@ -107,6 +107,22 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
             kernel_ms[k] += getattr(t, k) / args.encode_steps
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    # lossless round trip at full size: what the encoder wrote is decoded over the PCM it came from and every
+    # stream is hashed on the device against the signature of the source
+    rt = None
+    if not os.environ.get("FLAC_BENCH_NOCHECK"):
+        t0 = time.perf_counter()
+        dstreams = flac_amd.Decoder.make_streams(
+            (i * cap + 42, int(res[i].out_length) - 42, i * pcm_stride, pcm_bytes_per_file, infos[i % unique]) for i in range(nfiles))
+        dres = eng.decode_batch_device(d_enc, out_bytes, d_pcm, pcm_stride * nfiles, dstreams, hip_stream=hip_stream)
+        nfr = (nsamples + blocksize - 1) // blocksize
+        assert all(r.frames_ok == nfr and r.samples == nsamples for r in dres), "re-encoded streams did not decode completely"
+        digests = eng.md5_batch_device(d_pcm, pcm_stride * nfiles, [i * pcm_stride for i in range(nfiles)],
+                                       [pcm_bytes_per_file] * nfiles, hip_stream=hip_stream)
+        assert all(digests[i] == bytes(infos[i % unique].md5) for i in range(nfiles)), "re-encoded streams differ from the source PCM"
+        rt = {"streams": nfiles, "seconds": time.perf_counter() - t0}
+        if rank == 0:
+            log(f"encode -> decode round trip of all {nfiles} streams is lossless (MD5 on the device, {rt['seconds']:.2f} s)")
     flac_total = sum(int(r.out_length) for r in res)
     pcm_total = nfiles * pcm_bytes_per_file
     values = nfiles * nsamples * channels
@@ -116,7 +132,7 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
     return {"metric": "encoded PCM samples/sec (per GPU)", "value": values * args.encode_steps / elapsed, "unit": "samples/s",
             "steps": args.encode_steps, "ms_per_step": elapsed / args.encode_steps * 1e3, "flac_GB": flac_total / 1e9,
             "ratio": flac_total / pcm_total, "algorithmic_GB_per_s": alg * args.encode_steps / elapsed / 1e9,
-            "kernel_ms": kernel_ms, "cpu_baseline": cpu_enc,
+            "kernel_ms": kernel_ms, "cpu_baseline": cpu_enc, "round_trip_verified": rt,
             "roofline": {"bound": "hbm", "kernel": "k_enc_" + dom[:-3], "achieved": alg / a_s / 1e9 if a_s > 0 else 0.0, "peak": 8000.0,
                          "unit": "GB/s", "frac": alg / a_s / 1e9 / 8000.0 if a_s > 0 else 0.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kernel_ms[dom]}}
