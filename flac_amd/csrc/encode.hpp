@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace flacgpu {
 
 constexpr int kRun = 16;
@@ -344,14 +346,17 @@ __device__ inline int max_partition_order(uint32_t bs, uint32_t order, uint32_t 
     return L;
 }
 
-// Residual of a fixed predictor, 32-bit wrapping arithmetic.  w[M + j] is the lane's sample j.
-template <int M>
-__device__ inline void fixed_residual(const int32_t (&w)[M + kRun], int order, uint32_t (&u)[kRun])
+// Residual of a fixed predictor, 32-bit wrapping arithmetic.  xs: the block in LDS (see lds_pos), lbase: the
+// lane's run.
+__device__ inline void fixed_residual(const int32_t *xs, uint32_t lbase, int order, uint32_t (&u)[kRun])
 {
+    int32_t w[4 + kRun];
+#pragma unroll
+    for (int m = 0; m < 4 + kRun; ++m) w[m] = xs[lbase + lds_rel(m - 4)];
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
-        const uint32_t a = (uint32_t)w[M + j], b = (uint32_t)w[M + j - 1], c = (uint32_t)w[M + j - 2],
-                       d = (uint32_t)w[M + j - 3], e = (uint32_t)w[M + j - 4];
+        const uint32_t a = (uint32_t)w[4 + j], b = (uint32_t)w[3 + j], c = (uint32_t)w[2 + j], d = (uint32_t)w[1 + j],
+                       e = (uint32_t)w[j];
         uint32_t r;
         switch (order) {
         case 0: r = a; break;
@@ -379,37 +384,58 @@ __device__ inline uint32_t run_mask(uint32_t i0, uint32_t first, uint32_t end)
     return hi > lo ? ((1u << hi) - 1) & ~((1u << lo) - 1) : 0;
 }
 
-// LPC residual.  MODE 0: 24-bit multiply-adds (samples of at most 24 bits, coefficients of at most 15),
-// 1: 32-bit wrapping sums, 2: 64-bit sums.  The result is nonzero when some residual of the run may not
-// fit 32 bits (r + 2^31 - 1 has bits above 31 exactly when r is outside [-(2^31 - 1), 2^31 - 1]); the
-// caller then finds out which with lpc_residual_bad.
+// LPC residual of the lane's run.  xs / lbase: the block in LDS and the lane's run; cq: the M coefficients in
+// LDS (zero beyond the order).  MODE 0: 24-bit multiply-adds (samples of at most 24 bits, coefficients of at
+// most 15), 1: 32-bit wrapping sums, 2: 64-bit sums.  The taps are taken in passes of at most 16 so that a
+// pass's coefficients, its window of samples and the 16 running sums fit the registers of a 1024-lane
+// workgroup.  The result is nonzero when some residual of the run may not fit 32 bits (r + 2^31 - 1 has bits
+// above 31 exactly when r is outside [-(2^31 - 1), 2^31 - 1]); the caller then finds out which with
+// lpc_residual_bad.
 template <int M, int MODE>
-__device__ inline uint32_t lpc_residual(const int32_t (&w)[M + kRun], const int32_t (&cq)[M], int shift, uint32_t (&u)[kRun])
+__device__ inline uint32_t lpc_residual(const int32_t *xs, uint32_t lbase, const int32_t *cq, int shift, uint32_t (&u)[kRun])
 {
-    uint32_t high = 0;
+    constexpr int TP = M <= 16 ? M : 16;        // taps per pass
+    using acc_t = typename std::conditional<MODE == 2, int64_t, uint32_t>::type;
+    acc_t acc[kRun];
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) acc[j] = 0;
+#pragma unroll
+    for (int base = 0; base < M; base += TP) {
+        // the run's position goes through an empty asm so that the compiler treats every pass's window as
+        // loads of its own: it can neither start them before the previous pass's arithmetic nor merge the
+        // windows of the three arithmetic variants a caller branches between (which made all of them live)
+        uint32_t lb = lbase, cb = 0;
+        asm volatile("" : "+v"(lb), "+v"(cb));
+        int32_t c[TP], w[TP + kRun - 1];        // w[m] = sample (j - 1 - q) for m = (TP - 1 - qq) + j, q = base + qq
+#pragma unroll
+        for (int qq = 0; qq < TP; ++qq) c[qq] = cq[cb + base + qq];
+#pragma unroll
+        for (int m = 0; m < TP + kRun - 1; ++m) w[m] = xs[lb + lds_rel(m - TP - base)];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            if (MODE == 2) {
+#pragma unroll
+                for (int qq = 0; qq < TP; ++qq) acc[j] += (int64_t)c[qq] * (int64_t)w[TP - 1 - qq + j];
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int qq = 0; qq < TP; ++qq) acc[j] += (uint32_t)c[qq] * (uint32_t)w[TP - 1 - qq + j];
+            } else {
+                int32_t s0 = (int32_t)acc[j], s1 = 0;
+#pragma unroll
+                for (int qq = 0; qq < TP; qq += 2) {
+                    s0 = mad_i24(c[qq], w[TP - 1 - qq + j], s0);
+                    if (qq + 1 < TP) s1 = mad_i24(c[qq + 1], w[TP - 2 - qq + j], s1);
+                }
+                acc[j] = (acc_t)((uint32_t)s0 + (uint32_t)s1);
+            }
+        }
+    }
+    uint32_t high = 0, lb2 = lbase;
+    asm volatile("" : "+v"(lb2));
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
-        int64_t pred;
-        if (MODE == 2) {
-            int64_t s = 0;
-#pragma unroll
-            for (int q = 0; q < M; ++q) s += (int64_t)cq[q] * (int64_t)w[M + j - 1 - q];
-            pred = s >> shift;
-        } else if (MODE == 1) {
-            uint32_t s = 0;
-#pragma unroll
-            for (int q = 0; q < M; ++q) s += (uint32_t)cq[q] * (uint32_t)w[M + j - 1 - q];
-            pred = (int32_t)s >> shift;
-        } else {
-            int32_t s0 = 0, s1 = 0;
-#pragma unroll
-            for (int q = 0; q < M; q += 2) {
-                s0 = mad_i24(cq[q], w[M + j - 1 - q], s0);
-                if (q + 1 < M) s1 = mad_i24(cq[q + 1], w[M + j - 2 - q], s1);
-            }
-            pred = (int32_t)((uint32_t)s0 + (uint32_t)s1) >> shift;
-        }
-        const int64_t r = (int64_t)w[M + j] - pred;
+        const int64_t pred = MODE == 2 ? (int64_t)acc[j] >> shift : (int64_t)((int32_t)(uint32_t)acc[j] >> shift);
+        const int64_t r = (int64_t)xs[lb2 + j] - pred;
         high |= (uint32_t)((uint64_t)(r + 0x7FFFFFFFLL) >> 32);
         u[j] = fold((int32_t)r);
     }
@@ -418,21 +444,21 @@ __device__ inline uint32_t lpc_residual(const int32_t (&w)[M + kRun], const int3
 
 // Which residuals of the run do not fit 32 bits (bit j): the slow restatement of lpc_residual's test.
 template <int M>
-__device__ __noinline__ uint32_t lpc_residual_bad(const int32_t (&w)[M + kRun], const int32_t (&cq)[M], int shift, bool wide)
+__device__ __noinline__ uint32_t lpc_residual_bad(const int32_t *xs, uint32_t lbase, const int32_t *cq, int shift, bool wide)
 {
     uint32_t bad = 0;
     for (int j = 0; j < kRun; ++j) {
         int64_t pred;
         if (wide) {
             int64_t s = 0;
-            for (int q = 0; q < M; ++q) s += (int64_t)cq[q] * (int64_t)w[M + j - 1 - q];
+            for (int q = 0; q < M; ++q) s += (int64_t)cq[q] * (int64_t)xs[lbase + lds_rel(j - 1 - q)];
             pred = s >> shift;
         } else {
             uint32_t s = 0;
-            for (int q = 0; q < M; ++q) s += (uint32_t)cq[q] * (uint32_t)w[M + j - 1 - q];
+            for (int q = 0; q < M; ++q) s += (uint32_t)cq[q] * (uint32_t)xs[lbase + lds_rel(j - 1 - q)];
             pred = (int32_t)s >> shift;
         }
-        const int64_t r = (int64_t)w[M + j] - pred;
+        const int64_t r = (int64_t)xs[lbase + j] - pred;
         bad |= (uint32_t)((r != (int64_t)(int32_t)r) || (r == -2147483647LL - 1)) << j;
     }
     return bad;
@@ -946,26 +972,18 @@ __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ p
     const uint32_t i0 = t * kRun, lbase = lds_lane_base(t);
     const uint32_t mask_f = run_mask(i0, (uint32_t)fo, bs), mask_l = lpc_ok ? run_mask(i0, (uint32_t)ord, bs) : 0;
     uint32_t uf[kRun], ul[kRun];
-    {
-        int32_t w[M + kRun];
+    if (lpc_ok) {
+        uint32_t high;
+        if (wide) high = lpc_residual<M, 2>(xs, lbase, S.q, shift, ul);
+        else if (sb <= 24) high = lpc_residual<M, 0>(xs, lbase, S.q, shift, ul);
+        else high = lpc_residual<M, 1>(xs, lbase, S.q, shift, ul);
+        // only residuals that will be coded count
+        if (high && (lpc_residual_bad<M>(xs, lbase, S.q, shift, wide != 0) & mask_l)) atomicOr(&S.lpc_bad, 1u);
+    } else {
 #pragma unroll
-        for (int m = 0; m < M + kRun; ++m) w[m] = xs[lbase + lds_rel(m - M)];
-        if (lpc_ok) {
-            int32_t cq[M];
-#pragma unroll
-            for (int q = 0; q < M; ++q) cq[q] = S.q[q];
-            uint32_t high;
-            if (wide) high = lpc_residual<M, 2>(w, cq, shift, ul);
-            else if (sb <= 24) high = lpc_residual<M, 0>(w, cq, shift, ul);
-            else high = lpc_residual<M, 1>(w, cq, shift, ul);
-            // only residuals that will be coded count
-            if (high && (lpc_residual_bad<M>(w, cq, shift, wide != 0) & mask_l)) atomicOr(&S.lpc_bad, 1u);
-        } else {
-#pragma unroll
-            for (int j = 0; j < kRun; ++j) ul[j] = 0;
-        }
-        fixed_residual<M>(w, fo, uf);
+        for (int j = 0; j < kRun; ++j) ul[j] = 0;
     }
+    fixed_residual(xs, lbase, fo, uf);
     // residuals outside the coded range (warm-up, beyond the block) are cleared: the first and last waves only
     if (!__all(mask_f == 0xFFFFu && (!lpc_ok || mask_l == 0xFFFFu))) {
 #pragma unroll
@@ -1277,21 +1295,13 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
         pos += 6 + pbits;
         // residual codes
         uint32_t u[kRun];
-        {
-            int32_t w[M + kRun];
-#pragma unroll
-            for (int m = 0; m < M + kRun; ++m) w[m] = xs[lbase + lds_rel(m - M)];
-            if (type == 3) {
-                int32_t cq[M];
-#pragma unroll
-                for (int q = 0; q < M; ++q) cq[q] = q < 32 ? s_q[q] : 0;
-                const bool wide = (sb + (int)ph.prec + ilog2_32((uint32_t)order)) > 32;
-                if (wide) (void)lpc_residual<M, 2>(w, cq, ph.shift, u);
-                else if (sb <= 24) (void)lpc_residual<M, 0>(w, cq, ph.shift, u);
-                else (void)lpc_residual<M, 1>(w, cq, ph.shift, u);
-            } else {
-                fixed_residual<M>(w, order, u);
-            }
+        if (type == 3) {
+            const bool wide = (sb + (int)ph.prec + ilog2_32((uint32_t)order)) > 32;
+            if (wide) (void)lpc_residual<M, 2>(xs, lbase, s_q, ph.shift, u);
+            else if (sb <= 24) (void)lpc_residual<M, 0>(xs, lbase, s_q, ph.shift, u);
+            else (void)lpc_residual<M, 1>(xs, lbase, s_q, ph.shift, u);
+        } else {
+            fixed_residual(xs, lbase, order, u);
         }
         const uint32_t po = ph.po, psize = bs >> po;
         const uint32_t part = po ? i0 / psize : 0;
