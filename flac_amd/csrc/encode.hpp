@@ -254,11 +254,24 @@ __device__ inline void load_block_share(const uint8_t *src, uint32_t bs, int C, 
             const uint32_t i = t + (uint32_t)j * NT;
             lr[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)(i < bs ? i : bs - 1) * 4);
         }
+        // one loop per candidate: the choice is the same for the whole workgroup
+        if (cand == 0) {
 #pragma unroll
-        for (int j = 0; j < kRun; ++j) {
-            const int32_t l = (int32_t)(lr[j] << 16) >> 16, r = (int32_t)lr[j] >> 16;
-            const int32_t x = cand == 0 ? l : cand == 1 ? r : cand == 2 ? (l + r) >> 1 : l - r;
-            v[j] = t + (uint32_t)j * NT < bs ? x : 0;
+            for (int j = 0; j < kRun; ++j) v[j] = (int32_t)(lr[j] << 16) >> 16;
+        } else if (cand == 1) {
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) v[j] = (int32_t)lr[j] >> 16;
+        } else if (cand == 2) {
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) v[j] = (((int32_t)(lr[j] << 16) >> 16) + ((int32_t)lr[j] >> 16)) >> 1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) v[j] = ((int32_t)(lr[j] << 16) >> 16) - ((int32_t)lr[j] >> 16);
+        }
+        if (t + (uint32_t)(kRun - 1) * NT >= bs) {   // only blocks shorter than the workgroup's span
+#pragma unroll
+            for (int j = 0; j < kRun; ++j)
+                if (t + (uint32_t)j * NT >= bs) v[j] = 0;
         }
     } else {
 #pragma unroll
