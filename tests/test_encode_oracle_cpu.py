@@ -87,3 +87,42 @@ def test_oracle_encoder_compresses_like_the_corpus_encoder():
     g, _ = synth.encode(x, 16, 44100, synth.options(4096, 12))
     assert abs(len(f) - len(g)) <= 0.01 * len(g)
     assert len(f) < 0.7 * len(packed)
+
+
+def random_group(rng):
+    """A random encode call: options and 1-4 streams of random shape and signal kind."""
+    bs = int(rng.choice([16, 192, 576, 1000, 1024, 1152, 2304, 4096, 4608, 5000, 8192, 16384]))
+    order = int(rng.choice([0, 1, 4, 8, 12, 13, 20, 32]))
+    max_po = int(rng.integers(0, 9))
+    opts = dict(blocksize=bs, max_lpc_order=order, max_partition_order=max_po, min_partition_order=int(rng.integers(0, max_po + 1)),
+                stereo_mode=int(rng.integers(-1, 4)), qlp_precision=int(rng.choice([0, 0, 5, 9, 15])),
+                force_lpc_order=int(order if order and rng.random() < 0.25 else 0),
+                seektable_interval=int(rng.choice([0, 0, 1, 5])))
+    streams = []
+    for _ in range(int(rng.integers(1, 5))):
+        ch = int(rng.integers(1, 9))
+        bps = int(rng.choice([4, 8, 12, 16, 16, 20, 24, 24]))
+        n = int(rng.choice([0, 1, 15, 16, 17, bs - 1, bs, bs + 1, 2 * bs + 7, 3 * bs]))
+        n = min(n, 40000)
+        kind = str(rng.choice(["synth", "synth"] + SPECIAL_KINDS))
+        streams.append((ch, bps, int(rng.choice([8000, 44100, 48000, 96000, 12345])), n, kind))
+    return opts, streams
+
+
+def group_pcm(streams, bs, rng):
+    out = []
+    for i, (ch, bps, rate, n, kind) in enumerate(streams):
+        x = synth.pcm(1000 + i, n, ch, bps, rate, bs) if kind == "synth" or n == 0 else special_pcm(kind, n, ch, bps, rng)
+        out.append((synth.pack_pcm(x, bps) if n else b"", (n, rate, ch, bps)))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_encoder_random_groups(seed):
+    rng = np.random.default_rng(1000 + seed)
+    o, streams = random_group(rng)
+    opts = oracle.enc_options(**o)
+    for packed, shape in group_pcm(streams, o["blocksize"], rng):
+        n, rate, ch, bps = shape
+        f, nf, mn, mx = oracle.encode_stream(packed, n, ch, bps, rate, opts)
+        _check_file(f, packed, shape, opts)

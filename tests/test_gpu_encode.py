@@ -121,3 +121,17 @@ def test_encode_rejects_bad_arguments(decoder):
                        (0, 100000, 0, 2048, 44100, 2, 16), (0, 100, 0, 8192, 44100, 2, 16), (0, 100, 0, 2048, 0, 2, 16)):
         with pytest.raises(flac_amd.FlacError):
             decoder.encode_batch_device(d, 4096, d, 4096, decoder.make_pcm_streams([bad_stream]), flac_amd.encode_options())
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_encode_random_groups(decoder, seed):
+    """Random options and stream shapes (the CPU suite round-trips the same groups through the oracle)."""
+    from test_encode_oracle_cpu import group_pcm, random_group
+    rng = np.random.default_rng(1000 + seed)
+    o, streams = random_group(rng)
+    src = group_pcm(streams, o["blocksize"], rng)
+    packed = [p for p, _ in src]
+    shapes = [s for _, s in src]
+    gopts = flac_amd.encode_options(flags=flac_amd.ENC_MD5, **o)
+    files, res = gpu_encode_group(decoder, packed, shapes, gopts)
+    _check_against_oracle(files, res, packed, shapes, gopts, oracle.enc_options(**o))
