@@ -71,6 +71,35 @@ class Metadata(ctypes.Structure):
                 ("blocks", Block * MAX_BLOCKS), ("first_frame_offset", ctypes.c_uint64)]
 
 
+class VorbisCommentHead(ctypes.Structure):
+    _fields_ = [("vendor_offset", ctypes.c_uint32), ("vendor_length", ctypes.c_uint32), ("total_comments", ctypes.c_uint32)]
+
+
+class PictureHead(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ("picture_type", "mime_offset", "mime_length", "description_offset",
+                                               "description_length", "width", "height", "color_depth", "num_colors",
+                                               "length", "blob_offset", "blob_length")]
+
+
+class ApplicationHead(ctypes.Structure):
+    _fields_ = [("id", ctypes.c_uint32), ("data_offset", ctypes.c_uint32), ("data_length", ctypes.c_uint32)]
+
+
+class CuesheetIndex(ctypes.Structure):
+    _fields_ = [("sample_offset", ctypes.c_uint64), ("index_point", ctypes.c_uint8)]
+
+
+class CuesheetTrack(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_uint64), ("number", ctypes.c_uint8), ("isrc", ctypes.c_char * 12),
+                ("type", ctypes.c_uint8), ("pre_emphasis", ctypes.c_uint8), ("index_points", ctypes.c_uint8),
+                ("first_index", ctypes.c_uint32)]
+
+
+class CuesheetHead(ctypes.Structure):
+    _fields_ = [("media_catalog_number", ctypes.c_uint8 * 128), ("leadin_samples", ctypes.c_uint64),
+                ("is_compact_disc", ctypes.c_uint8), ("total_tracks", ctypes.c_uint8)]
+
+
 class Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("flags", ctypes.c_uint32),
                 ("reserved", ctypes.c_uint32)]
@@ -146,6 +175,8 @@ EXPORTS = [
     "flacgpu_decode_batch_device", "flacgpu_decode_batch", "flacgpu_get_timing",
     "flacgpu_encode_bound", "flacgpu_encode_batch_device", "flacgpu_encode_batch", "flacgpu_get_encode_timing",
     "flacgpu_md5_batch_device", "flacgpu_seektable_bytes",
+    "flacgpu_parse_vorbis_comment", "flacgpu_parse_picture", "flacgpu_picture_type_string", "flacgpu_parse_application",
+    "flacgpu_parse_cuesheet",
 ]
 
 _lib = None
@@ -178,6 +209,15 @@ def lib():
         L.flacgpu_parse_streaminfo.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(StreamInfo)]
         L.flacgpu_parse_seektable.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(SeekPoint), sz, ctypes.POINTER(sz)]
         L.flacgpu_parse_metadata.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(Metadata)]
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        L.flacgpu_parse_vorbis_comment.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(VorbisCommentHead), u32p, u32p, sz,
+                                                   ctypes.POINTER(sz)]
+        L.flacgpu_parse_picture.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(PictureHead)]
+        L.flacgpu_picture_type_string.restype = ctypes.c_char_p
+        L.flacgpu_picture_type_string.argtypes = [ctypes.c_uint32]
+        L.flacgpu_parse_application.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ApplicationHead)]
+        L.flacgpu_parse_cuesheet.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(CuesheetHead), ctypes.POINTER(CuesheetTrack), sz,
+                                             ctypes.POINTER(CuesheetIndex), sz, ctypes.POINTER(sz)]
         L.flacgpu_status_string.restype = ctypes.c_char_p
         L.flacgpu_status_string.argtypes = [ctypes.c_int]
         L.flacgpu_create.argtypes = [ctypes.POINTER(Options), ctypes.POINTER(vp)]
@@ -240,6 +280,70 @@ def parse_seektable(b: bytes):
     if rc:
         raise FlacError(rc)
     return [pts[i] for i in range(n.value)]
+
+
+def parse_vorbis_comment(b: bytes) -> dict:
+    """MarshalVorbisCommentBlock, flacmeta.go:720-746 -> {Vendor, TotalComments, Comments}."""
+    b = bytes(b)
+    head, n = VorbisCommentHead(), ctypes.c_size_t()
+    rc = lib().flacgpu_parse_vorbis_comment(b, len(b), ctypes.byref(head), None, None, 0, ctypes.byref(n))
+    if rc:
+        raise FlacError(rc)
+    offs, lens = (ctypes.c_uint32 * max(1, n.value))(), (ctypes.c_uint32 * max(1, n.value))()
+    rc = lib().flacgpu_parse_vorbis_comment(b, len(b), ctypes.byref(head), offs, lens, n.value, ctypes.byref(n))
+    if rc:
+        raise FlacError(rc)
+    return {"Vendor": b[head.vendor_offset: head.vendor_offset + head.vendor_length].decode("utf-8", "replace"),
+            "TotalComments": head.total_comments,
+            "Comments": [b[offs[i]: offs[i] + lens[i]].decode("utf-8", "replace") for i in range(n.value)]}
+
+
+def parse_picture(b: bytes) -> dict:
+    """MarshalPictureBlock, flacmeta.go:554-604 -> the fields of PictureBlock."""
+    b = bytes(b)
+    p = PictureHead()
+    rc = lib().flacgpu_parse_picture(b, len(b), ctypes.byref(p))
+    if rc:
+        raise FlacError(rc)
+    return {"PictureType": lib().flacgpu_picture_type_string(p.picture_type).decode(),
+            "MimeType": b[p.mime_offset: p.mime_offset + p.mime_length].decode("ascii", "replace"),
+            "Description": b[p.description_offset: p.description_offset + p.description_length].decode("utf-8", "replace"),
+            "Width": p.width, "Height": p.height, "ColorDepth": p.color_depth, "NumColors": p.num_colors,
+            "Length": p.length, "PictureBlob": b[p.blob_offset: p.blob_offset + p.blob_length]}
+
+
+def parse_application(b: bytes) -> dict:
+    """MarshalApplicationBlock, flacmeta.go:349-366 (the data starts at byte 32, as in the reference)."""
+    b = bytes(b)
+    a = ApplicationHead()
+    rc = lib().flacgpu_parse_application(b, len(b), ctypes.byref(a))
+    if rc:
+        raise FlacError(rc)
+    return {"Id": a.id, "Data": b[a.data_offset: a.data_offset + a.data_length]}
+
+
+def parse_cuesheet(b: bytes) -> dict:
+    """MarshalCuesheetBlock, flacmeta.go:369-432 -> the fields of CuesheetBlock with its tracks and indexes."""
+    b = bytes(b)
+    head, ni = CuesheetHead(), ctypes.c_size_t()
+    rc = lib().flacgpu_parse_cuesheet(b, len(b), ctypes.byref(head), None, 0, None, 0, ctypes.byref(ni))
+    if rc:
+        raise FlacError(rc)
+    tracks = (CuesheetTrack * max(1, head.total_tracks))()
+    idx = (CuesheetIndex * max(1, ni.value))()
+    rc = lib().flacgpu_parse_cuesheet(b, len(b), ctypes.byref(head), tracks, head.total_tracks, idx, ni.value, ctypes.byref(ni))
+    if rc:
+        raise FlacError(rc)
+    out = {"MediaCatalogNumber": bytes(head.media_catalog_number), "LeadinSamples": head.leadin_samples,
+           "IsCompactDisc": bool(head.is_compact_disc), "TotalTracks": head.total_tracks, "Tracks": []}
+    for i in range(head.total_tracks):
+        t = tracks[i]
+        out["Tracks"].append({"Offset": t.offset, "Number": t.number,
+                              "ISRC": ctypes.string_at(ctypes.addressof(t) + CuesheetTrack.isrc.offset, 12),   # NULs kept
+                              "Type": t.type, "PreEmphasis": bool(t.pre_emphasis), "IndexPoints": t.index_points,
+                              "Indexes": [(idx[t.first_index + j].sample_offset, idx[t.first_index + j].index_point)
+                                          for j in range(t.index_points)]})
+    return out
 
 
 def parse_metadata(buf: bytes) -> Metadata:

@@ -2,9 +2,8 @@
 // (flacmeta.go): the same type and field names, the same block numbering, Read() leaving the stream on
 // byte 0 of audio frame 0, errors as returned strings where Go returns `error` (empty = nil).
 //
-// Only the blocks the frame engine needs (STREAMINFO, SEEKTABLE, PADDING) and VORBIS_COMMENT are carried
-// with their payload; APPLICATION, CUESHEET and PICTURE blocks are walked over (their headers are kept in
-// Blocks), as the frame path has no use for them.
+// Every block kind of the reference is carried with its payload (STREAMINFO, SEEKTABLE, PADDING,
+// VORBIS_COMMENT, APPLICATION, CUESHEET, PICTURE); all parsing is done by the C ABI.
 //
 // The frame engine itself (Decoder) has no counterpart in the reference, which stops at the first frame
 // (flacmeta.go:845-849); it takes what Read left behind.
@@ -90,7 +89,50 @@ struct VorbisCommentBlock {    // flacmeta.go:276-280
     }
 };
 
+struct ApplicationBlock {      // flacmeta.go:197-200
+    uint32_t Id = 0;
+    std::vector<uint8_t> Data;
+};
+
+struct TrackIndex {            // flacmeta.go:228-232
+    uint64_t SampleOffset = 0;
+    uint8_t IndexPoint = 0;
+    bool operator==(const TrackIndex &o) const { return SampleOffset == o.SampleOffset && IndexPoint == o.IndexPoint; }
+};
+
+struct CuesheetTrack {         // flacmeta.go:214-225
+    uint64_t Offset = 0;
+    uint8_t Number = 0;
+    std::string ISRC;          // 12 bytes, NULs kept
+    uint8_t Type = 0;
+    bool PreEmphasis = false;
+    uint8_t IndexPoints = 0;
+    std::vector<TrackIndex> Indexes;
+    bool operator==(const CuesheetTrack &o) const
+    {
+        return Offset == o.Offset && Number == o.Number && ISRC == o.ISRC && Type == o.Type && PreEmphasis == o.PreEmphasis &&
+               IndexPoints == o.IndexPoints && Indexes == o.Indexes;
+    }
+};
+
+struct CuesheetBlock {         // flacmeta.go:203-211
+    std::string MediaCatalogNumber;   // 128 bytes, NUL padding kept (flacmeta.go:403)
+    uint64_t LeadinSamples = 0;
+    bool IsCompactDisc = false;
+    uint8_t TotalTracks = 0;
+    std::vector<CuesheetTrack> Tracks;
+};
+
+struct PictureBlock {          // flacmeta.go:243-253
+    std::string PictureType, MimeType, Description;
+    uint32_t Width = 0, Height = 0, ColorDepth = 0, NumColors = 0, Length = 0;
+    std::vector<uint8_t> PictureBlob;
+};
+
 // Complete blocks (header + data), flacmeta.go:288-334.
+struct Application { MetadataBlockHeader Header; ApplicationBlock Data; bool IsPopulated = false; };
+struct Cuesheet { MetadataBlockHeader Header; CuesheetBlock Data; bool IsPopulated = false; };
+struct Picture { MetadataBlockHeader Header; PictureBlock Data; bool IsPopulated = false; };
 struct Padding { MetadataBlockHeader Header; bool IsPopulated = false; };
 struct Streaminfo { MetadataBlockHeader Header; StreaminfoBlock Data; bool IsPopulated = false; };
 struct VorbisComment { MetadataBlockHeader Header; VorbisCommentBlock Data; bool IsPopulated = false; };
@@ -112,9 +154,12 @@ inline std::string hex(const uint8_t *b, size_t n)
 // Metadata, flacmeta.go:337-346.
 struct Metadata {
     flac::Streaminfo Streaminfo;
+    flac::Application Application;
     flac::VorbisComment VorbisComment;
+    std::vector<flac::Picture> Pictures;
     flac::Padding Padding;
     flac::Seektable Seektable;
+    flac::Cuesheet Cuesheet;
     std::vector<MetadataBlockHeader> Blocks;   // every block in file order, payloads not kept
     uint8_t TotalBlocks = 0;
     uint64_t FirstFrameOffset = 0;             // where Read leaves the stream
@@ -148,6 +193,8 @@ struct Metadata {
         if (int rc = flacgpu_parse_metadata(buf.data(), buf.size(), &md)) {
             if (rc == FLACGPU_ERR_DUPLICATE) return "two blocks of a kind that may appear once encountered";
             if (rc == FLACGPU_ERR_SEEKTABLE) return "SEEKTABLE block length is not a multiple of 18";
+            if (rc == FLACGPU_ERR_CUESHEET) return "invalid CUESHEET block";
+            if (rc == FLACGPU_ERR_APPLICATION) return "malformed ApplictionBlock; field length not a multiple of 8";
             return std::string("metadata: ") + flacgpu_status_string(rc);
         }
         FirstFrameOffset = md.first_frame_offset;
@@ -184,20 +231,69 @@ struct Metadata {
                 break;
             }
             case MetadataVorbisComment: {
-                // MarshalVorbisCommentBlock, flacmeta.go:720-746: little-endian lengths, vendor, then the comments
+                // MarshalVorbisCommentBlock, flacmeta.go:720-746
                 VorbisComment.Header = h; VorbisComment.IsPopulated = true;
-                auto le32 = [&](size_t o) { return (uint32_t)p[o] | (uint32_t)p[o + 1] << 8 | (uint32_t)p[o + 2] << 16 | (uint32_t)p[o + 3] << 24; };
-                size_t o = 0;
-                if (b.length < 8) return "VORBIS_COMMENT block too short";
-                const uint32_t vl = le32(o); o += 4;
-                if (o + vl + 4 > b.length) return "VORBIS_COMMENT block too short";
-                VorbisComment.Data.Vendor.assign(reinterpret_cast<const char *>(p + o), vl); o += vl;
-                VorbisComment.Data.TotalComments = le32(o); o += 4;
-                for (uint32_t k = 0; k < VorbisComment.Data.TotalComments; ++k) {
-                    if (o + 4 > b.length) return "VORBIS_COMMENT block too short";
-                    const uint32_t cl = le32(o); o += 4;
-                    if (o + cl > b.length) return "VORBIS_COMMENT block too short";
-                    VorbisComment.Data.Comments.emplace_back(reinterpret_cast<const char *>(p + o), cl); o += cl;
+                flacgpu_vorbis_comment v;
+                size_t n = 0;
+                if (int rc = flacgpu_parse_vorbis_comment(p, b.length, &v, nullptr, nullptr, 0, &n))
+                    return std::string("VORBIS_COMMENT: ") + flacgpu_status_string(rc);
+                std::vector<uint32_t> off(n + 1), len(n + 1);
+                if (int rc = flacgpu_parse_vorbis_comment(p, b.length, &v, off.data(), len.data(), n, &n))
+                    return std::string("VORBIS_COMMENT: ") + flacgpu_status_string(rc);
+                VorbisComment.Data.Vendor.assign(reinterpret_cast<const char *>(p + v.vendor_offset), v.vendor_length);
+                VorbisComment.Data.TotalComments = v.total_comments;
+                for (size_t k = 0; k < n; ++k)
+                    VorbisComment.Data.Comments.emplace_back(reinterpret_cast<const char *>(p + off[k]), len[k]);
+                break;
+            }
+            case MetadataApplication: {
+                // MarshalApplicationBlock, flacmeta.go:349-366
+                Application.Header = h; Application.IsPopulated = true;
+                flacgpu_application a;
+                if (int rc = flacgpu_parse_application(p, b.length, &a)) return std::string("APPLICATION: ") + flacgpu_status_string(rc);
+                Application.Data.Id = a.id;
+                Application.Data.Data.assign(p + a.data_offset, p + a.data_offset + a.data_length);
+                break;
+            }
+            case MetadataPicture: {
+                // MarshalPictureBlock, flacmeta.go:554-604; pictures may repeat (flacmeta.go:799-801)
+                flacgpu_picture pic;
+                if (int rc = flacgpu_parse_picture(p, b.length, &pic)) return std::string("PICTURE: ") + flacgpu_status_string(rc);
+                flac::Picture pc;
+                pc.Header = h; pc.IsPopulated = true;
+                pc.Data.PictureType = flacgpu_picture_type_string(pic.picture_type);
+                pc.Data.MimeType.assign(reinterpret_cast<const char *>(p + pic.mime_offset), pic.mime_length);
+                pc.Data.Description.assign(reinterpret_cast<const char *>(p + pic.description_offset), pic.description_length);
+                pc.Data.Width = pic.width; pc.Data.Height = pic.height; pc.Data.ColorDepth = pic.color_depth;
+                pc.Data.NumColors = pic.num_colors; pc.Data.Length = pic.length;
+                pc.Data.PictureBlob.assign(p + pic.blob_offset, p + pic.blob_offset + pic.blob_length);
+                Pictures.push_back(pc);
+                break;
+            }
+            case MetadataCuesheet: {
+                // MarshalCuesheetBlock / Track / TrackIndex, flacmeta.go:369-516
+                Cuesheet.Header = h; Cuesheet.IsPopulated = true;
+                flacgpu_cuesheet c;
+                size_t ni = 0;
+                if (int rc = flacgpu_parse_cuesheet(p, b.length, &c, nullptr, 0, nullptr, 0, &ni))
+                    return std::string("CUESHEET: ") + flacgpu_status_string(rc);
+                std::vector<flacgpu_cuesheet_track> tr(c.total_tracks);
+                std::vector<flacgpu_cuesheet_index> ix(ni + 1);
+                if (int rc = flacgpu_parse_cuesheet(p, b.length, &c, tr.data(), tr.size(), ix.data(), ix.size(), &ni))
+                    return std::string("CUESHEET: ") + flacgpu_status_string(rc);
+                CuesheetBlock &d = Cuesheet.Data;
+                d.MediaCatalogNumber.assign(c.media_catalog_number, 128);
+                d.LeadinSamples = c.leadin_samples; d.IsCompactDisc = c.is_compact_disc != 0; d.TotalTracks = c.total_tracks;
+                for (const flacgpu_cuesheet_track &t : tr) {
+                    CuesheetTrack ct;
+                    ct.Offset = t.offset; ct.Number = t.number; ct.ISRC.assign(t.isrc, 12); ct.Type = t.type;
+                    ct.PreEmphasis = t.pre_emphasis != 0; ct.IndexPoints = t.index_points;
+                    for (uint32_t j = 0; j < t.index_points; ++j) {
+                        TrackIndex ti;
+                        ti.SampleOffset = ix[t.first_index + j].sample_offset; ti.IndexPoint = ix[t.first_index + j].index_point;
+                        ct.Indexes.push_back(ti);
+                    }
+                    d.Tracks.push_back(ct);
                 }
                 break;
             }

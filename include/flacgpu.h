@@ -45,7 +45,9 @@ enum {
     FLACGPU_ERR_CAPACITY = 8,    /* caller's output array too small                     */
     FLACGPU_ERR_DEVICE = 9,      /* HIP runtime error; see flacgpu_last_error           */
     FLACGPU_ERR_NOMEM = 10,
-    FLACGPU_ERR_UNSUPPORTED = 11
+    FLACGPU_ERR_UNSUPPORTED = 11,
+    FLACGPU_ERR_CUESHEET = 12,   /* no tracks, track number 0, index offset not a multiple of 588 (flacmeta.go:409, :473, :511) */
+    FLACGPU_ERR_APPLICATION = 13 /* data length not a multiple of 8 (flacmeta.go:361) */
 };
 
 /* Per-frame status in flacgpu_frame.status. */
@@ -127,6 +129,67 @@ int flacgpu_parse_seektable(const uint8_t *b, size_t n, flacgpu_seekpoint *out, 
 
 /* (*Metadata).Read, flacmeta.go:749-850: marker, block loop, duplicate rules. */
 int flacgpu_parse_metadata(const uint8_t *buf, size_t len, flacgpu_metadata *out);
+
+/* The payload parsers below restate the reference's remaining Marshal* functions.  They
+ * allocate nothing: strings and blobs are reported as (offset, length) into the payload the
+ * caller passed.  A payload too short for its own fields, which makes the reference panic
+ * (it slices without a length check), yields FLACGPU_ERR_TRUNCATED. */
+
+/* VorbisCommentBlock, flacmeta.go:276-280; MarshalVorbisCommentBlock, flacmeta.go:720-746
+ * (lengths are little-endian, :736-741).  offsets / lengths: one entry per comment. */
+typedef struct flacgpu_vorbis_comment {
+    uint32_t vendor_offset, vendor_length;
+    uint32_t total_comments;
+} flacgpu_vorbis_comment;
+int flacgpu_parse_vorbis_comment(const uint8_t *b, size_t n, flacgpu_vorbis_comment *out,
+                                 uint32_t *offsets, uint32_t *lengths, size_t cap, size_t *count);
+
+/* PictureBlock, flacmeta.go:243-253; MarshalPictureBlock, flacmeta.go:554-604. */
+typedef struct flacgpu_picture {
+    uint32_t picture_type;          /* numeric; flacgpu_picture_type_string gives the reference's name */
+    uint32_t mime_offset, mime_length;
+    uint32_t description_offset, description_length;
+    uint32_t width, height, color_depth, num_colors;
+    uint32_t length;                /* Length field */
+    uint32_t blob_offset, blob_length;   /* blob_length = min(length, bytes left), as buf.Next gives */
+} flacgpu_picture;
+int flacgpu_parse_picture(const uint8_t *b, size_t n, flacgpu_picture *out);
+/* PictureType / PictureTypes, flacmeta.go:117-139, :165-171: "UNKNOWN" above 20. */
+const char *flacgpu_picture_type_string(uint32_t picture_type);
+
+/* ApplicationBlock, flacmeta.go:197-200; MarshalApplicationBlock, flacmeta.go:349-366.  The
+ * reference takes ApplicationIdLen (a bit count, 32) as a byte count (:360): the id is the
+ * first 4 bytes, the data starts at byte 32.  Restated as it behaves. */
+typedef struct flacgpu_application {
+    uint32_t id;
+    uint32_t data_offset, data_length;
+} flacgpu_application;
+int flacgpu_parse_application(const uint8_t *b, size_t n, flacgpu_application *out);
+
+/* CuesheetBlock / CuesheetTrack / TrackIndex, flacmeta.go:203-232; MarshalCuesheetBlock,
+ * MarshalCuesheetTrack, MarshalCuesheetTrackIndex, flacmeta.go:369-516. */
+typedef struct flacgpu_cuesheet_index {
+    uint64_t sample_offset;
+    uint8_t  index_point;
+} flacgpu_cuesheet_index;
+typedef struct flacgpu_cuesheet_track {
+    uint64_t offset;
+    uint8_t  number;
+    char     isrc[12];
+    uint8_t  type;              /* 0 audio, 1 non-audio */
+    uint8_t  pre_emphasis;
+    uint8_t  index_points;
+    uint32_t first_index;       /* position of this track's first index in the index array */
+} flacgpu_cuesheet_track;
+typedef struct flacgpu_cuesheet {
+    char     media_catalog_number[128];   /* NUL padding kept, as the reference keeps it (:403) */
+    uint64_t leadin_samples;
+    uint8_t  is_compact_disc;
+    uint8_t  total_tracks;
+} flacgpu_cuesheet;
+int flacgpu_parse_cuesheet(const uint8_t *b, size_t n, flacgpu_cuesheet *out,
+                           flacgpu_cuesheet_track *tracks, size_t track_cap,
+                           flacgpu_cuesheet_index *indexes, size_t index_cap, size_t *n_indexes);
 
 const char *flacgpu_status_string(int status);
 

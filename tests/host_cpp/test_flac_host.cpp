@@ -106,13 +106,34 @@ static void stereo(const std::string &dir, bool gpu)
                                                   {105984, 30284, 4608}, {18446744073709551615ull, 0, 0}};
     CHECK(got.Seektable.IsPopulated && got.Seektable.Header == hdr(flac::MetadataSeektable, 108, false) && got.Seektable.Data == st);
     CHECK(got.Padding.IsPopulated && got.Padding.Header == hdr(flac::MetadataPadding, 3060, true));
-    // the blocks this layer walks over: their headers as the reference reports them (flacmeta_test.go:163, :249)
-    bool cue = false, pic = false;
-    for (const auto &b : got.Blocks) {
-        if (b == hdr(flac::MetadataCuesheet, 588, false)) cue = true;
-        if (b == hdr(flac::MetadataPicture, 199, false)) pic = true;
+    // CUESHEET, flacmeta_test.go:154-217
+    {
+        const flac::Cuesheet &c = got.Cuesheet;
+        CHECK(c.IsPopulated && c.Header == hdr(flac::MetadataCuesheet, 588, false));
+        std::string catalog = "1234567890123";
+        catalog.resize(128, '\0');
+        const std::string none(12, '\0');
+        CHECK(c.Data.MediaCatalogNumber == catalog && c.Data.LeadinSamples == 0x15888 && c.Data.IsCompactDisc && c.Data.TotalTracks == 4);
+        std::vector<flac::CuesheetTrack> want(4);
+        want[0].Offset = 0; want[0].Number = 1; want[0].ISRC = "123456789012"; want[0].IndexPoints = 1; want[0].Indexes = {{0, 1}};
+        want[1].Offset = 44100; want[1].Number = 2; want[1].ISRC = none; want[1].Type = 1; want[1].PreEmphasis = true;
+        want[1].IndexPoints = 2; want[1].Indexes = {{0, 1}, {588, 2}};
+        want[2].Offset = 88200; want[2].Number = 3; want[2].ISRC = none; want[2].IndexPoints = 1; want[2].Indexes = {{0, 1}};
+        want[3].Offset = 162496; want[3].Number = 170; want[3].ISRC = none;
+        CHECK(c.Data.Tracks == want);
     }
-    CHECK(cue && pic);
+    // PICTURE, flacmeta_test.go:239-264
+    {
+        CHECK(got.Pictures.size() == 1);
+        const flac::Picture &p = got.Pictures[0];
+        CHECK(p.IsPopulated && p.Header == hdr(flac::MetadataPicture, 199, false));
+        CHECK(p.Data.PictureType == "Cover (front)" && p.Data.MimeType == "image/png" && p.Data.Description == "A pixel.");
+        CHECK(p.Data.Width == 1 && p.Data.Height == 1 && p.Data.ColorDepth == 24 && p.Data.NumColors == 0 && p.Data.Length == 150);
+        CHECK(p.Data.PictureBlob.size() == 150 && p.Data.PictureBlob[0] == 0x89 && p.Data.PictureBlob[1] == 'P' &&
+              p.Data.PictureBlob[148] == 0x60 && p.Data.PictureBlob[149] == 0x82);
+        CHECK(flac::hex(p.Data.PictureBlob.data(), 8) == "89504e470d0a1a0a");
+    }
+    CHECK(!got.Application.IsPopulated);
     CHECK((uint64_t)f.tellg() == got.FirstFrameOffset && got.FirstFrameOffset == 4186);
     if (gpu) {
         flac::Decoder dec;
