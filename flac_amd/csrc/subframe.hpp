@@ -46,6 +46,16 @@ constexpr uint32_t kNoFill = 0xFFFFFFFFu;
 #endif
 constexpr uint32_t kSkimPairK = FLACGPU_SKIM_PAIR_K;
 
+// a * b + c on the low 24 bits of a and b (sign-extended), low 32 bits of the result: one full-rate
+// instruction where a 32-bit multiply takes four.  Exact whenever a and b fit 24 bits.  Written as
+// asm because the compiler only selects it when it can see both sign-extensions in the same block.
+__device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
+{
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // MSB-first reader over one lane's bitstream.  Its whole state is a bit position P, counted from the
 // 64-byte-aligned address at or before the frame's first byte.  Stream word w of the lane sits at
 // ring[(w % kRingWords) * 64] (ring already points at the lane's column), byte order corrected; the ring
@@ -98,16 +108,18 @@ struct BitReader {
         fill = (P >> 5) & ~(kUnitWords - 1);   // ring restarts at this unit; until it is refilled, words come from global memory
     }
     __device__ inline uint32_t pos() const { return P; }
-    // The 32 bits at P when both words are known to be in the ring (the speculative loops, which test
-    // `starved` afterwards instead).
-    __device__ inline uint32_t peek_ring() const
+    // The 32 bits at P for the speculative loops, which assume both words are in the ring (and test
+    // `starved` afterwards) and keep the position negated: Q = -P (mod 2^32).  Bit P sits in
+    // word (P - 1) / 32 at offset ((P - 1) % 32) + 1, counted 1 .. 32, so the window is that word and the
+    // next funnel-shifted right by (32 - offset) = Q % 32: one instruction, and no special case when P is a
+    // multiple of 32.  The word's ring slot is 31 - (Q / 32) % 32.
+    __device__ inline uint32_t peek_ring_neg(uint32_t Q) const
     {
-        const uint32_t *q = ring + ((P >> 5) & (kRingWords - 1)) * 64;
-        uint2 t;              // the later word first: it is the low half of the 64-bit window
-        t.x = q[64];
-        t.y = q[0];
-        const uint64_t win = (((uint64_t)t.y) << 32) | t.x;
-        return (uint32_t)((win << (P & 31)) >> 32);
+        typedef __attribute__((address_space(3))) const uint32_t lds_word;
+        const uint32_t top = (uint32_t)(uintptr_t)(lds_word *)(ring + (kRingWords - 1) * 64);   // LDS byte address of slot 31
+        const uint32_t idx = __builtin_amdgcn_ubfe(Q, 5, 5);
+        lds_word *q = (lds_word *)(uintptr_t)mad_i24((int32_t)idx, -256, (int32_t)top);
+        return __builtin_amdgcn_alignbit(q[0], q[64], Q);
     }
     __device__ inline bool starved() const { return (P >> 5) + 1 >= fill; }
     __device__ inline uint32_t peek() const
@@ -196,16 +208,6 @@ __device__ inline uint32_t read_unary(BitReader &br, uint32_t limit)
     return q + z;
 }
 
-// a * b + c on the low 24 bits of a and b (sign-extended), low 32 bits of the result: one full-rate
-// instruction where a 32-bit multiply takes four.  Exact whenever a and b fit 24 bits.  Written as
-// asm because the compiler only selects it when it can see both sign-extensions in the same block.
-__device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
-{
-    int32_t r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // Leading zeros of w; 0xFFFFFFFF when w is zero (the hardware's answer, without the clamp to 32 that
 // __clz adds).  The speculative loops keep the largest count they saw and test it once per group.
 __device__ inline uint32_t lead_zeros_raw(uint32_t w)
@@ -213,6 +215,14 @@ __device__ inline uint32_t lead_zeros_raw(uint32_t w)
     uint32_t q;
     asm("v_ffbh_u32 %0, %1" : "=v"(q) : "v"(w));
     return q;
+}
+
+// `width` bits of w from bit (offset mod 32) up: the instruction takes the offset's low five bits itself.
+__device__ inline uint32_t bfe_mod32(uint32_t w, uint32_t offset, uint32_t width)
+{
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "v"(offset), "v"(width));
+    return r;
 }
 
 __device__ inline int32_t unzigzag(uint32_t u) { return (int32_t)((u >> 1) ^ (0u - (u & 1))); }
@@ -407,29 +417,32 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
                 // costs the whole wave a walk through the group.  With Rice parameter k the unary parts of a pair
                 // may total 30 - 2k.  The limit on k is tuned on synthetic audio (7: 26 % slower than 9; 9, 11, 14 equal).
                 const bool pairs = __all(!reads || k <= kSkimPairK);
+                uint32_t Q = 0u - br.P;   // the read position, negated (see peek_ring_neg)
                 if (pairs) {
                     // two codes per window: the second is read from the window shifted by the first
 #pragma unroll
                     for (int P = 0; P < (int)G / 2; ++P) {
-                        const uint32_t w = br.peek_ring();
+                        const uint32_t w = br.peek_ring_neg(Q);
                         const uint32_t n1 = __clz(w) + 1 + k;
                         const uint32_t w2 = w << (n1 & 31);
                         const uint32_t tot = n1 + __clz(w2) + 1 + k;
                         longest = max(longest, tot);
-                        br.P += tot;
+                        Q -= tot;
                     }
                 } else {
 #pragma unroll
                     for (int P = 0; P < (int)G; ++P) {
                         if (P == (int)kRoundSteps) {
+                            br.P = 0u - Q;
                             starved = starved || br.starved();
                             ring_round(br, rf, reads, in_vec, in_vecs, wave_ring, lane);
                         }
-                        const uint32_t nb = __clz(br.peek_ring()) + 1 + k;
+                        const uint32_t nb = __clz(br.peek_ring_neg(Q)) + 1 + k;
                         longest = max(longest, nb);
-                        br.P += nb;
+                        Q -= nb;
                     }
                 }
+                br.P = 0u - Q;
                 starved = starved || br.starved();
                 redo = reads && (starved || longest > 32);
                 if (on && !redo) part_rem -= G;
@@ -831,26 +844,31 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             for (int j = 0; j < NT; ++j) s_hist[j] = ring[U - 1 - j];
             uint32_t longest_q = 0;
             bool starved = false;
+            uint32_t Q = 0u - br.P;              // the read position, negated (see peek_ring_neg)
+            const uint32_t neg_k1 = 0u - (k + 1);
 #pragma unroll
             for (int P = 0; P < U; ++P) {
                 if (P && P % kRoundSteps == 0) {
+                    br.P = 0u - Q;
                     starved = starved || br.starved();
                     ring_round(br, rf, rice_on, in_vec, p.in_vecs, wave_ring, lane);
                 }
-                // Rice code: unary part = leading zeros of the window, then k low bits
-                const uint32_t w = br.peek_ring();
+                // Rice code: unary part = leading zeros of the window, then k low bits.  The code's length
+                // nb = q + 1 + k is kept negated: -nb mod 32 is where the low bits start, and it advances Q.
+                const uint32_t w = br.peek_ring_neg(Q);
                 const uint32_t q = lead_zeros_raw(w);
                 longest_q |= q;
-                const uint32_t nb = q + 1 + k;
-                const uint32_t low = __builtin_amdgcn_ubfe(w, 32 - nb, k);
+                const uint32_t neg_nb = neg_k1 - q;
+                const uint32_t low = bfe_mod32(w, neg_nb, k);
                 const int32_t res = unzigzag((q << k) | low);
-                br.P += nb;
+                Q += neg_nb;
                 const int32_t pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
                 const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
                 ring[P] = v;
                 emit(v, on, (uint32_t)P & (kT - 1), std::true_type{});
                 if (U > (int)kTile && P == (int)kTile - 1) flush(n0);
             }
+            br.P = 0u - Q;
             starved = starved || br.starved();
 #ifdef FLACGPU_DEBUG_FORCE_REDO
             redo = rice_on;
