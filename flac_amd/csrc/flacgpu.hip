@@ -339,7 +339,8 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
     const uint64_t in_vecs = (in_bytes + 15) / 16;
     for (const Run &r : runs) {
         const uint32_t nf = r.r_end - r.r_begin;
-        k_skim<<<(nf + 255) / 256, 256, 0, st>>>((const uint8_t *)d_in, in_vecs, c, r.r_begin, r.r_end, r.C);
+        k_skim<<<(nf + 255) / 256, 256, 0, st>>>((const uint8_t *)d_in, in_vecs, c, r.r_begin, r.r_end, r.C,
+                                                 (const uint4 *)h->crc_tables.p);
     }
     mark(h, EV_SKIM, st);
     for (const Run &r : runs) {
@@ -349,6 +350,7 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
         const uint32_t blocks = (waves + 3) / 4;
         DecodeParams p;
         p.in = (const uint8_t *)d_in; p.in_vecs = in_vecs; p.out = (uint8_t *)d_out;
+        p.spare = (const uint4 *)h->crc_tables.p;
         p.streams = (const StreamDev *)h->streams.p; p.c = c;
         p.r_begin = r.r_begin; p.r_end = r.r_end; p.C = r.C; p.B = r.B;
         p.class_flags = (uint32_t *)h->counter.p + 4;

@@ -65,9 +65,9 @@ __device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
 // stops at its frame's bit limit).
 struct BitReader {
     const uint32_t *gbase;   // global words from the aligned base
+    const uint4 *spare;      // 32 readable bytes of device memory, the same for every lane
     uint32_t nwords;         // words readable from gbase
     uint32_t *ring;
-    uint64_t gvec;           // vector (16-byte) index of gbase in the input buffer
     uint32_t fill;
     uint32_t P;              // bit position
 
@@ -88,18 +88,20 @@ struct BitReader {
         if (w < fill) return ring[(w & (kRingWords - 1)) * 64];
         return gload(w);
     }
-    __device__ inline void init(const uint8_t *in, uint64_t in_vecs, uint64_t goff, uint32_t *lane_ring)
+    // spare: 32 readable bytes of device memory, loaded (and ignored) by lanes that have nothing to fetch
+    // (all from the same address: one cache line per wave instruction, not 64)
+    __device__ inline void init(const uint8_t *in, uint64_t in_vecs, uint64_t goff, uint32_t *lane_ring, const uint4 *spare)
     {
         const uint64_t b = goff & ~(uint64_t)63;
         gbase = reinterpret_cast<const uint32_t *>(in + b);
-        gvec = b >> 4;
-        nwords = (uint32_t)min((in_vecs - gvec) * 4, (uint64_t)0xFFFFFFFFu);
+        nwords = (uint32_t)min((in_vecs - (b >> 4)) * 4, (uint64_t)0xFFFFFFFFu);
+        this->spare = spare;
         ring = lane_ring;
         fill = P = 0;
     }
-    __device__ inline void null(uint32_t *lane_ring)
+    __device__ inline void null(uint32_t *lane_ring, const uint4 *spare)
     {
-        gbase = nullptr; nwords = 0; ring = lane_ring; gvec = 0;
+        gbase = nullptr; this->spare = spare; nwords = 0; ring = lane_ring;
         fill = P = 0;
     }
     __device__ inline void seek(uint32_t bitpos)
@@ -156,16 +158,16 @@ struct RingFetch {
 //   1. commit: the 32 bytes loaded in the previous round are written to the ring (unless
 //      the reader has been repositioned since);
 //   2. issue: a lane with 17 or fewer unread words loads its next 32 bytes, to be
-//      committed in the next round.
+//      committed in the next round.  Only whole 32-byte units inside the input are fetched:
+//      the last few bytes of the input buffer, when they do not fill one, are read word by
+//      word (BitReader::gload).
 // A lane that starts a round with at least 10 unread words has the two words of its window in
 // the ring until the next round, whatever it consumes in between (at most 8 words), so the
 // decode loops never wait for memory.  After repositioning, three rounds in a row restore the margin.
 // Each lane loads for itself: 64 lanes touch 64 different lines either way, and the two 16-byte
 // loads of a lane fall into one 32-byte sector.
-__device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active, const uint4 *in_vec, uint64_t in_vecs,
-                                  uint32_t *wave_ring, uint32_t lane)
+__device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active)
 {
-    (void)wave_ring; (void)lane;
     // ---- commit
     if (rf.at == br.fill) {   // a valid `fill` is never kNoFill
         const uint32_t slot = br.fill & (kRingWords - 1);   // a multiple of 8
@@ -185,13 +187,13 @@ __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active, con
     // ---- issue
     const uint32_t rdw = br.P >> 5;
     if (active && (int32_t)(br.fill - rdw) < -(int32_t)kUnitWords + 1) br.fill = rdw & ~(kUnitWords - 1);
-    const bool want = active && (int32_t)(br.fill - rdw) <= 17;
+    const bool want = active && (int32_t)(br.fill - rdw) <= 17 && br.fill + kUnitWords <= br.nwords;
     rf.at = want ? br.fill : kNoFill;
-    // the loads are unconditional (a lane with nothing to fetch re-reads vector 0): a branch around
-    // them would make the compiler copy the result, and so wait for it, right here
-    const uint64_t v_idx = br.gvec + (br.fill >> 2), v_last = in_vecs - 1;   // never past the input
-    rf.v[0] = in_vec[want ? (v_idx < v_last ? v_idx : v_last) : 0];
-    rf.v[1] = in_vec[want ? (v_idx + 1 < v_last ? v_idx + 1 : v_last) : 0];
+    // the loads are unconditional (a lane with nothing to fetch reads the spare bytes): a branch
+    // around them would make the compiler copy the result, and so wait for it, right here
+    const uint4 *src = want ? reinterpret_cast<const uint4 *>(br.gbase + br.fill) : br.spare;
+    rf.v[0] = src[0];
+    rf.v[1] = src[1];
 }
 
 // Unary-coded count: zeros up to and including the terminating one are consumed.
@@ -314,7 +316,7 @@ __device__ inline uint32_t wave_max_u32(uint32_t v)
 // parameters are small: a lane whose codes did not fit (or whose ring ran dry)
 // is rolled back and walks the group code by code.
 __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, uint64_t in_vecs, CandArrays c,
-                                              uint32_t r_begin, uint32_t r_end, uint32_t C)
+                                              uint32_t r_begin, uint32_t r_end, uint32_t C, const uint4 *spare)
 {
     __shared__ __align__(16) uint32_t s_ring[4 * kRingSlots * 64];
     constexpr uint32_t G = 16;
@@ -324,20 +326,19 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
     bool active = r < r_end;
     if (active) active = c.status[r] == kFrameOK;
     BitReader br;
-    br.null(wave_ring + lane);
+    br.null(wave_ring + lane, spare);
     uint32_t bs = 0, bps = 0, ca = 0, limit = 0;
     if (active) {
         const uint32_t info = c.info[r];
         bs = info_bs(info); bps = info_bps(info); ca = info_ca(info);
         const uint64_t goff = c.goff[r];
-        br.init(in, in_vecs, goff, wave_ring + lane);
+        br.init(in, in_vecs, goff, wave_ring + lane, spare);
         const uint32_t a = (uint32_t)(goff & 63);
         limit = (a + c.len[r]) * 8;   // first bit after the frame
         br.seek((a + info_hl(info)) * 8);
     }
     bool alive = active;
     int rc = kFrameOK;
-    const uint4 *in_vec = reinterpret_cast<const uint4 *>(in);
     RingFetch rf;
     rf.clear();
 
@@ -397,11 +398,11 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
             if (part_rem == 0) rice = false;   // no partition left
         };
 
-        ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
-        ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+        ring_round(br, rf, rice);
+        ring_round(br, rf, rice);
         const uint32_t bs_max = wave_max_u32(rice ? bs : 0);
         for (uint32_t n0 = 0; n0 < bs_max; n0 += G) {
-            ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+            ring_round(br, rf, rice);
             if (rice && n0 < bs && br.pos() > limit) kill(kFrameTruncated);
             if (rice && n0 < bs && part_rem == 0 && n0 >= order) open_partition();
             const bool on = rice && n0 < bs;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
                         if (P == (int)kRoundSteps) {
                             br.P = 0u - Q;
                             starved = starved || br.starved();
-                            ring_round(br, rf, reads, in_vec, in_vecs, wave_ring, lane);
+                            ring_round(br, rf, reads);
                         }
                         const uint32_t nb = __clz(br.peek_ring_neg(Q)) + 1 + k;
                         longest = max(longest, nb);
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
             }
             if (run_generic) {
                 for (uint32_t n = n0; n < n0 + G; ++n) {
-                    if (n - n0 == kRoundSteps) ring_round(br, rf, rice, in_vec, in_vecs, wave_ring, lane);
+                    if (n - n0 == kRoundSteps) ring_round(br, rf, rice);
                     if (redo && rice && n >= order && n < bs) {
                         if (part_rem == 0) open_partition();
                         if (rice) {
@@ -477,6 +478,7 @@ struct DecodeParams {
     uint64_t in_vecs;      // 16-byte vectors readable from `in`
     uint8_t *out;
     const StreamDev *streams;
+    const uint4 *spare;    // 32 readable bytes of device memory (see BitReader::init)
     CandArrays c;
     uint32_t r_begin, r_end;
     uint32_t C;            // channels of every frame in [r_begin, r_end)
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     SubHdr h;
     h.kind = 0; h.order = 0; h.lpc = 0; h.wasted = 0; h.sbps = 0;
     BitReader br;
-    br.null(wave_ring + lane);
+    br.null(wave_ring + lane, p.spare);
     uint64_t dst = 0;
     if (active) {
         const uint32_t info = p.c.info[r];
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
         const StreamDev &s = p.streams[p.c.stream[r]];
         bs = info_bs(info); ca = info_ca(info);
         limit = ((uint32_t)(goff & 63) + p.c.len[r]) * 8;
-        br.init(p.in, p.in_vecs, goff, wave_ring + lane);
+        br.init(p.in, p.in_vecs, goff, wave_ring + lane, p.spare);
         br.seek(p.c.subpos[(uint64_t)r * 8 + ch]);
         const uint64_t first = info_var(info) ? p.c.num[r] : p.c.num[r] * (uint64_t)s.max_bs;
         dst = s.out_off + first * CB;   // from p.out
@@ -807,15 +809,14 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 
     // One extra group runs past the end of the block when some lane's subframe is all warm-up
     // samples: its predictor parameters still have to be consumed.
-    const uint4 *in_vec = reinterpret_cast<const uint4 *>(p.in);
     RingFetch rf;
     rf.clear();
-    ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
-    ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
+    ring_round(br, rf, active && status == kFrameOK);
+    ring_round(br, rf, active && status == kFrameOK);
     const bool trailing = __any(active && status == kFrameOK && kind == 2 && order >= bs);
     const uint32_t n_end = ((bs_max + U - 1) / U) * U + (trailing ? U : 0);
     for (uint32_t n0 = 0; n0 < n_end; n0 += U) {
-        ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
+        ring_round(br, rf, active && status == kFrameOK);
         const bool on = active && status == kFrameOK && n0 < bs;
         if (on && kind == 2 && started && part_rem == 0) next_partition();
         if (on && br.pos() > limit) status = kFrameTruncated;
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 if (P && P % kRoundSteps == 0) {
                     br.P = 0u - Q;
                     starved = starved || br.starved();
-                    ring_round(br, rf, rice_on, in_vec, p.in_vecs, wave_ring, lane);
+                    ring_round(br, rf, rice_on);
                 }
                 // Rice code: unary part = leading zeros of the window, then k low bits.  The code's length
                 // nb = q + 1 + k is kept negated: -nb mod 32 is where the low bits start, and it advances Q.
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             for (int j = 0; j < NT; ++j) hist[j] = ring[U - 1 - j];
             for (uint32_t n = n0; n < n0 + U; ++n) {
                 if (n != n0 && ((n - n0) % kRoundSteps) == 0)
-                    ring_round(br, rf, active && status == kFrameOK, in_vec, p.in_vecs, wave_ring, lane);
+                    ring_round(br, rf, active && status == kFrameOK);
                 if (U > (int)kTile && n - n0 == kTile) flush(n0);
                 const bool ok = active && status == kFrameOK && redo;
                 const bool live = ok && n < bs;
