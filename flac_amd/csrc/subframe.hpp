@@ -35,12 +35,19 @@ namespace flacgpu {
 // owns a small ring in LDS that it refills 32 bytes (one sector) at a time
 // (ring_round).  A refill is issued one round (8 decode steps) before it is
 // written to the ring, so its latency overlaps decoding.
-constexpr uint32_t kRingWords = 32;   // ring capacity per lane, in 32-bit words
-constexpr uint32_t kRingSlots = 33;   // slot 32 repeats slot 0, so that words w and w + 1 are always one two-word read
+#ifndef FLACGPU_RING_LOG2
+#define FLACGPU_RING_LOG2 5
+#endif
+constexpr uint32_t kRingLog2 = FLACGPU_RING_LOG2;
+constexpr uint32_t kRingWords = 1u << kRingLog2;   // ring capacity per lane, in 32-bit words
+constexpr uint32_t kRingSlots = kRingWords + 1;    // the last slot repeats slot 0, so that words w and w + 1 are always one two-word read
 constexpr uint32_t kUnitWords = 8;    // refill granule: 32 bytes
 constexpr uint32_t kRoundSteps = 8;   // decode steps (of at most 32 bits) between refill rounds
 constexpr uint32_t kRingBytesPerWave = kRingSlots * 64 * 4;
 constexpr uint32_t kNoFill = 0xFFFFFFFFu;
+// A lane fetches its next unit when it has this many unread words or fewer.  The unit lands one round later
+// on the ring's oldest words, which the reader must have passed by then: at most kRingWords - kUnitWords.
+constexpr uint32_t kFetchBelow = kRingWords >= 32 ? 17 : kRingWords - kUnitWords;
 #ifndef FLACGPU_SKIM_PAIR_K
 #define FLACGPU_SKIM_PAIR_K 9
 #endif
@@ -119,7 +126,7 @@ struct BitReader {
     {
         typedef __attribute__((address_space(3))) const uint32_t lds_word;
         const uint32_t top = (uint32_t)(uintptr_t)(lds_word *)(ring + (kRingWords - 1) * 64);   // LDS byte address of slot 31
-        const uint32_t idx = __builtin_amdgcn_ubfe(Q, 5, 5);
+        const uint32_t idx = __builtin_amdgcn_ubfe(Q, 5, kRingLog2);
         lds_word *q = (lds_word *)(uintptr_t)mad_i24((int32_t)idx, -256, (int32_t)top);
         return __builtin_amdgcn_alignbit(q[0], q[64], Q);
     }
@@ -187,7 +194,7 @@ __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active)
     // ---- issue
     const uint32_t rdw = br.P >> 5;
     if (active && (int32_t)(br.fill - rdw) < -(int32_t)kUnitWords + 1) br.fill = rdw & ~(kUnitWords - 1);
-    const bool want = active && (int32_t)(br.fill - rdw) <= 17 && br.fill + kUnitWords <= br.nwords;
+    const bool want = active && (int32_t)(br.fill - rdw) <= (int32_t)kFetchBelow && br.fill + kUnitWords <= br.nwords;
     rf.at = want ? br.fill : kNoFill;
     // the loads are unconditional (a lane with nothing to fetch reads the spare bytes): a branch
     // around them would make the compiler copy the result, and so wait for it, right here
@@ -895,10 +902,21 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             int32_t hist[NT];   // hist[j] = sample n-1-j
 #pragma unroll
             for (int j = 0; j < NT; ++j) hist[j] = ring[U - 1 - j];
+            // A group of two tiles: the lanes that keep their fast-group results have the second tile's
+            // samples in the staging columns, and this loop writes the first tile out again.  They stage
+            // each tile again from their history registers (ring[P] = sample n0 + P of the group).
+            auto restage = [&](int first) {
+                if (!redo) {
+#pragma unroll
+                    for (int P = 0; P < (int)kTile; ++P)
+                        tile_raw[(uint32_t)P * kRawStride + lane] = (uint32_t)ring[(first + P) % U] << h.wasted;
+                }
+            };
+            if (U > (int)kTile) restage(0);
             for (uint32_t n = n0; n < n0 + U; ++n) {
                 if (n != n0 && ((n - n0) % kRoundSteps) == 0)
                     ring_round(br, rf, active && status == kFrameOK);
-                if (U > (int)kTile && n - n0 == kTile) flush(n0);
+                if (U > (int)kTile && n - n0 == kTile) { flush(n0); restage((int)kTile); }
                 const bool ok = active && status == kFrameOK && redo;
                 const bool live = ok && n < bs;
                 if (ok && kind == 2 && !started && n >= order) {

@@ -103,6 +103,32 @@ def test_long_rice_codes(decoder):
         assert r.frames_ok == ost.frames_ok == 4
 
 
+def test_long_rice_codes_among_32_tap_neighbours(decoder):
+    """The same spikes with order-32 predictors, where a group of the unrolled loop is two write-out tiles
+    long: the first tile has already been written when a lane is rolled back, and the generic loop writes
+    it again for the whole wave.  Only channel 0 has spikes, so every wave mixes redone lanes with lanes
+    that keep their results; both tiles of both kinds must come out right (16-bit: 24-bit multiplies,
+    24-bit: 64-bit sums)."""
+    rng = np.random.default_rng(11)
+    files, srcs = [], []
+    for ch, bps in ((2, 16), (8, 24), (3, 24)):
+        n = 4096 * 3 + 333
+        x = rng.integers(-300, 300, size=(n, ch)).astype(np.int32)
+        x[:, 1:] += (2000 * np.sin(np.arange(n) / 9.0))[:, None].astype(np.int32)
+        x[:, 0] = rng.integers(-3, 4, size=n)
+        spikes = rng.integers(64, n, size=40)
+        x[spikes, 0] = rng.choice([-(1 << (bps - 1)), (1 << (bps - 1)) - 1], size=40)
+        f, _ = synth.encode(x, bps, 48000, synth.options(4096, 32, force_lpc_order=32, force_partition_order=0, stereo_mode=0))
+        files.append(bytes(f))
+        srcs.append(synth.pack_pcm(x, bps))
+    pcms, res, infos = gpu_batch(decoder, files, out_fill=0x55)
+    for f, p, src, si, r in zip(files, pcms, srcs, infos, res):
+        want, ost = oracle_decode(si, split_file(f)[1])
+        assert bytes(want) == src
+        assert np.array_equal(p, want)
+        assert r.frames_ok == ost.frames_ok == 4
+
+
 def test_device_md5_matches_streaminfo(decoder, testdata):
     """flacgpu_md5_batch_device on the decoded PCM still in HBM: equals hashlib and the STREAMINFO
     signatures the reference's tests assert (flacmeta_test.go:37, :121), for lengths around the 64-byte
