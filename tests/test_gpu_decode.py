@@ -129,6 +129,29 @@ def test_long_rice_codes_among_32_tap_neighbours(decoder):
         assert r.frames_ok == ost.frames_ok == 4
 
 
+def test_full_scale_noise_outruns_the_refill_schedule(decoder):
+    """White noise at full scale is incompressible: nearly bps bits per code, so the lanes consume their
+    bit-reader rings as fast as the refill rounds can fill them and some run dry inside the unrolled loop
+    (rolled back and redone).  Quiet channels beside the loud ones keep their results."""
+    rng = np.random.default_rng(23)
+    files, srcs = [], []
+    for ch, bps, order, bs in ((2, 16, 8, 4096), (2, 24, 12, 4096), (8, 24, 32, 4096), (4, 20, 32, 1024), (1, 8, 4, 576)):
+        n = bs * 3 + 57
+        lim = 1 << (bps - 1)
+        x = rng.integers(-lim, lim, size=(n, ch)).astype(np.int32)
+        if ch > 2:
+            x[:, ch // 2] = rng.integers(-5, 6, size=n)
+        f, _ = synth.encode(x, bps, 48000, synth.options(bs, order, stereo_mode=0))
+        files.append(bytes(f))
+        srcs.append(synth.pack_pcm(x, bps))
+    pcms, res, infos = gpu_batch(decoder, files, out_fill=0x33)
+    for f, p, src, si, r in zip(files, pcms, srcs, infos, res):
+        want, ost = oracle_decode(si, split_file(f)[1])
+        assert bytes(want) == src
+        assert np.array_equal(p, want)
+        assert r.frames_ok == ost.frames_ok == 4
+
+
 def test_device_md5_matches_streaminfo(decoder, testdata):
     """flacgpu_md5_batch_device on the decoded PCM still in HBM: equals hashlib and the STREAMINFO
     signatures the reference's tests assert (flacmeta_test.go:37, :121), for lengths around the 64-byte
