@@ -349,10 +349,10 @@ def main():
         # comes from the committed rocprofv3 --pmc passes over this same command (profiles/), scaled by files
         traffic, traffic_note = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_c_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_g_pmc_traffic.json")))
             kd = pmc["kernels"]["k_decode<12, 0, true>"]
             traffic = (2.0 * kd["FETCH_SIZE_KiB"] + kd["WRITE_SIZE_KiB"]) * 1024.0 * nfiles / pmc["files"]
-            traffic_note = (f"(2 x FETCH_SIZE + WRITE_SIZE) of k_decode from profiles/r1_c_pmc_traffic.json, measured at "
+            traffic_note = (f"(2 x FETCH_SIZE + WRITE_SIZE) of k_decode from profiles/r1_g_pmc_traffic.json, measured at "
                             f"{pmc['files']} files and scaled to {nfiles}; the factor 2 is calibrated for coalesced reads "
                             f"only and is an upper bound for this kernel's 32-byte sector reads")
         except (OSError, KeyError, ValueError):
