@@ -503,10 +503,13 @@ constexpr uint32_t kRawStride = 66;   // words per sample column of the tile: 64
                                       // 8-byte reads of 16-bit stereo (16 lanes: 4 frames x 4 columns) cover all banks once
 
 // LDS bytes one wave needs: the refill ring, the sample tile (one 32-bit word per lane and sample: samples are
-// staged as coded, whatever the output format) and per-frame destination, block size and channel assignment.
+// staged as coded, whatever the output format).  Three blocks of four waves fit a CU's 160 KiB; a per-frame
+// table of destinations and block sizes beside the tile made that two for mono streams (64 frames per wave),
+// so what the write-out needs to know about a frame comes from the frame's first lane by a lane read instead.
 __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 {
-    return kRingBytesPerWave + kTile * kRawStride * 4 + (64 / C) * 16;
+    (void)C;
+    return kRingBytesPerWave + kTile * kRawStride * 4;
 }
 
 // One lane per (frame, channel); a wave holds floor(64 / C) frames.
@@ -537,13 +540,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
     const uint32_t F = 64 / C;
     const uint32_t wave_bytes = decode_wave_lds(C);
-    const uint32_t tile_bytes = kTile * kRawStride * 4;
     uint32_t *wave_ring = reinterpret_cast<uint32_t *>(smem + wave_in_block * wave_bytes);
     uint8_t *tile = smem + wave_in_block * wave_bytes + kRingBytesPerWave;
     uint32_t *tile_raw = reinterpret_cast<uint32_t *>(tile);
-    uint64_t *s_dst = reinterpret_cast<uint64_t *>(tile + tile_bytes);
-    uint32_t *s_bs = reinterpret_cast<uint32_t *>(s_dst + F);
-    uint32_t *s_mode = s_bs + F;
 
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const uint32_t fl = lane / C, ch = lane - fl * C;
@@ -592,7 +591,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     }
 
     const uint32_t bs_max = wave_max_u32(active ? bs : 0);
-    if (fl < F && ch == 0) { s_dst[fl] = dst; s_bs[fl] = active ? bs : 0; s_mode[fl] = ca; }
+    // a frame's destination, block size (bits 0-19; 0 when the frame is not decoded) and channel assignment
+    // (bits 20-23), as held by the lane of its first channel
+    const uint32_t my_meta = (active ? bs : 0) | (ca << 20);
+    auto frame_dst = [&](uint32_t f) { return (uint64_t)__shfl((unsigned long long)dst, (int)(f * C)); };
+    auto frame_meta = [&](uint32_t f) { return (uint32_t)__shfl((int)my_meta, (int)(f * C)); };
     // whole-dword write-out needs every frame's destination 4-byte aligned (a tile row of kTile samples is a
     // whole number of dwords for every sample size and channel count)
     const bool dwords = !__any(active && ((reinterpret_cast<uint64_t>(p.out) + dst) & 3));
@@ -608,13 +611,41 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // it = 0 .. 3.  Divisions by C and 4C are multiplications by rounded-up 16-bit reciprocals (exact while
     // dividend x divisor < 2^16; dividends here are below 256, divisors at most 32).
     const uint32_t inv_c = 65536u / C + 1, inv_4c = 65536u / (4 * C) + 1;
+    // What never changes from one write-out to the next is worked out once per item: the LDS addresses of
+    // its four slots (the block's LDS is below 64 KiB), where its dwords go (offset from p.out of the frame's
+    // first tile), and in one word the frame's block size (bits 0-19; 0 for an item beyond the wave's
+    // frames), the sample column of its last slot (20-23) and the channel assignment (24-27).
+    typedef __attribute__((address_space(3))) const uint32_t lds_word;
+    uint32_t q_src[4][4] = {};
+    uint64_t q_dst[4] = {};
+    uint32_t q_meta[4] = {};
     if (STEREO16) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const uint32_t f = it * 16 + (lane >> 2);
-            modes |= (s_mode[f] & 15u) << (4 * it);
-            fdst[it] = s_dst[f] + (lane & 3) * 16;
-            fbs[it] = s_bs[f];
+            const uint32_t meta = frame_meta(f);
+            modes |= ((meta >> 20) & 15u) << (4 * it);
+            fdst[it] = frame_dst(f) + (lane & 3) * 16;
+            fbs[it] = meta & 0xFFFFFu;
+        }
+    } else {
+        const uint32_t tile_lds = (uint32_t)(uintptr_t)(lds_word *)tile_raw;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t item = it * 64 + lane, f = (item * inv_4c) >> 16, g = item - f * 4 * C;
+            const bool ok = f < F;
+            uint32_t col = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t slot = 4 * g + j;
+                col = (slot * inv_c) >> 16;
+                q_src[it][j] = tile_lds + (ok ? (col * kRawStride + f * C + (slot - col * C)) * 4 : 0u);
+            }
+            const uint32_t fc = ok ? f : 0u;
+            const uint64_t dst_f = frame_dst(fc);
+            const uint32_t meta = frame_meta(fc);
+            q_dst[it] = ok ? dst_f + g * 4 * B : 0;
+            q_meta[it] = ok ? (meta & 0xFFFFFu) | (col << 20) | (((meta >> 20) & 15u) << 24) : 0u;
         }
     }
 
@@ -766,13 +797,53 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 }
             }
         } else {
+            // the 4 * B output bytes of four slots as dwords d0 .. d(B-1); B == 4: the slots themselves
+            auto pack = [&](const uint32_t (&v)[4], uint32_t &d0, uint32_t &d1, uint32_t &d2) {
+                if (B == 1) d0 = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
+                if (B == 2) { d0 = (v[0] & 0xFFFFu) | (v[1] << 16); d1 = (v[2] & 0xFFFFu) | (v[3] << 16); }
+                if (B == 3) {
+                    d0 = (v[0] & 0xFFFFFFu) | (v[1] << 24);
+                    d1 = ((v[1] >> 8) & 0xFFFFu) | (v[2] << 16);
+                    d2 = ((v[2] >> 16) & 0xFFu) | (v[3] << 8);
+                }
+            };
+            // Items whose four slots all exist in the frame and whose destination is dword aligned (all but a
+            // block's ragged last tile): everything about them but t0 was worked out before the sample loop.
+            bool ragged = false;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const uint32_t fbs_f = q_meta[it] & 0xFFFFFu;
+                if (t0 >= fbs_f) continue;
+                if (!dwords || ((q_meta[it] >> 20) & 15u) >= fbs_f - t0) { ragged = true; continue; }
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = *(lds_word *)(uintptr_t)q_src[it][j];
+                if (C == 2) {
+                    const uint32_t m = q_meta[it] >> 24;
+                    uint32_t L, R;
+                    decorrelate(m, v[0], v[1], L, R); v[0] = L; v[1] = R;
+                    decorrelate(m, v[2], v[3], L, R); v[2] = L; v[3] = R;
+                }
+                uint32_t d0 = v[0], d1 = v[1], d2 = v[2];
+                pack(v, d0, d1, d2);
+                uint32_t *q = reinterpret_cast<uint32_t *>(p.out + q_dst[it] + (uint64_t)t0 * CB);
+                q[0] = d0;
+                if (B >= 2) q[1] = d1;
+                if (B >= 3) q[2] = d2;
+                if (B >= 4) q[3] = v[3];
+            }
+            if (__any(ragged))
 #pragma unroll 1
             for (uint32_t it = 0; it < 4; ++it) {
                 const uint32_t item = it * 64 + lane, f = (item * inv_4c) >> 16, g = item - f * 4 * C;
+                const uint32_t fc = f < F ? f : 0u;
+                const uint64_t dst_f = frame_dst(fc);      // lane reads: before the lanes part ways
+                const uint32_t meta = frame_meta(fc);
                 if (f >= F) continue;
-                const uint32_t fbs_f = s_bs[f];
+                const uint32_t fbs_f = meta & 0xFFFFFu;
                 if (t0 >= fbs_f) continue;
                 const uint32_t ncols = min(kTile, fbs_f - t0);   // sample columns of this tile that exist in the frame
+                if (dwords && ((4 * g + 3) * inv_c >> 16) < ncols) continue;   // written above
                 uint32_t v[4], nvalid = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -781,34 +852,17 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                     nvalid += col < ncols ? 1u : 0u;
                 }
                 if (C == 2) {   // slots are (a, b) of two consecutive samples
-                    const uint32_t m = s_mode[f] & 15u;
+                    const uint32_t m = (meta >> 20) & 15u;
                     uint32_t L, R;
                     decorrelate(m, v[0], v[1], L, R); v[0] = L; v[1] = R;
                     decorrelate(m, v[2], v[3], L, R); v[2] = L; v[3] = R;
                 }
-                // the 4 * B output bytes as dwords d0 .. d(B-1)
-                uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];   // B == 4
-                if (B == 1) d0 = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
-                if (B == 2) { d0 = (v[0] & 0xFFFFu) | (v[1] << 16); d1 = (v[2] & 0xFFFFu) | (v[3] << 16); }
-                if (B == 3) {
-                    d0 = (v[0] & 0xFFFFFFu) | (v[1] << 24);
-                    d1 = ((v[1] >> 8) & 0xFFFFu) | (v[2] << 16);
-                    d2 = ((v[2] >> 16) & 0xFFu) | (v[3] << 8);
-                }
-                uint8_t *at = p.out + s_dst[f] + (uint64_t)t0 * CB + g * 4 * B;
-                if (dwords && nvalid == 4) {
-                    uint32_t *q = reinterpret_cast<uint32_t *>(at);   // 4-byte aligned; wider stores would need more
-                    q[0] = d0;
-                    if (B >= 2) q[1] = d1;
-                    if (B >= 3) q[2] = d2;
-                    if (B >= 4) q[3] = d3;
-                } else {
-                    // a block that ends inside these four slots, or an odd destination: byte by byte
+                // a block that ends inside these four slots, or an odd destination: byte by byte
+                uint8_t *at = p.out + dst_f + (uint64_t)t0 * CB + g * 4 * B;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if ((uint32_t)j < nvalid)
-                            for (uint32_t y = 0; y < B; ++y) at[j * B + y] = (uint8_t)(v[j] >> (8 * y));
-                }
+                for (int j = 0; j < 4; ++j)
+                    if ((uint32_t)j < nvalid)
+                        for (uint32_t y = 0; y < B; ++y) at[j * B + y] = (uint8_t)(v[j] >> (8 * y));
             }
         }
         __builtin_amdgcn_wave_barrier();
