@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 #pragma unroll
     for (int j = 0; j < U; ++j) ring[j] = 0;
     uint32_t shift = 0;
-    bool wide = false, started = false;
+    bool started = false;
     const uint32_t kind = active ? h.kind : 0;
     const uint32_t order = h.order;
     int32_t constval = 0;
@@ -677,7 +677,6 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 if ((uint32_t)j < order) coef[j] = br.read_signed(prec);
-            wide = (h.sbps + prec + (31 - __clz(order))) > 32;
         } else {
             if (order == 1) { coef[0] = 1; }
             if (order == 2) { coef[0] = 2; coef[1] = -1; }
@@ -730,7 +729,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 if (j % 3 == 1) s0 += m; else if (j % 3 == 2) s1 += m; else s2 += m;
             }
             const int64_t sum = (s0 + s1) + s2 + (int64_t)coef[0] * (int64_t)tap(0);
-            return wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum) >> shift;
+            // A lane whose own subframe does not need 64 bits (sbps + precision + floor(log2(order)) <= 32, so
+            // its sum fits 32 bits) gets the same low word from the 64-bit shift as from a 32-bit one.
+            return (int32_t)(sum >> shift);
         } else if (ARITH == 1) {
             uint32_t s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
