@@ -498,6 +498,11 @@ struct DecodeParams {
 // order among its lanes.  U = history ring size and unroll factor, NT = taps.
 __host__ __device__ constexpr int class_unroll(int nt) { return nt <= 16 ? 16 : 32; }
 
+// 2, 3 and 4 dwords at a dword-aligned address
+struct __attribute__((packed, aligned(4))) Dwords2 { uint32_t a, b; };
+struct __attribute__((packed, aligned(4))) Dwords3 { uint32_t a, b, c; };
+struct __attribute__((packed, aligned(4))) Dwords4 { uint32_t a, b, c, d; };
+
 constexpr uint32_t kTile = 16;        // samples staged in LDS between write-outs
 constexpr uint32_t kRawStride = 66;   // words per sample column of the tile: 64 lanes + 2, so that the write-out's
                                       // 8-byte reads of 16-bit stereo (16 lanes: 4 frames x 4 columns) cover all banks once
@@ -827,11 +832,13 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 }
                 uint32_t d0 = v[0], d1 = v[1], d2 = v[2];
                 pack(v, d0, d1, d2);
-                uint32_t *q = reinterpret_cast<uint32_t *>(p.out + q_dst[it] + (uint64_t)t0 * CB);
-                q[0] = d0;
-                if (B >= 2) q[1] = d1;
-                if (B >= 3) q[2] = d2;
-                if (B >= 4) q[3] = v[3];
+                // one store per item: multi-dword global stores need dword alignment only, and a wave's stores
+                // count against the same counter as its refill loads, so fewer of them wait less
+                uint8_t *q = p.out + q_dst[it] + (uint64_t)t0 * CB;
+                if (B == 1) *reinterpret_cast<uint32_t *>(q) = d0;
+                else if (B == 2) *reinterpret_cast<Dwords2 *>(q) = Dwords2{d0, d1};
+                else if (B == 3) *reinterpret_cast<Dwords3 *>(q) = Dwords3{d0, d1, d2};
+                else *reinterpret_cast<Dwords4 *>(q) = Dwords4{d0, d1, d2, v[3]};
             }
             if (__any(ragged))
 #pragma unroll 1
