@@ -835,6 +835,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 // one store per item: multi-dword global stores need dword alignment only, and a wave's stores
                 // count against the same counter as its refill loads, so fewer of them wait less
                 uint8_t *q = p.out + q_dst[it] + (uint64_t)t0 * CB;
+#ifdef FLACGPU_DEBUG_NO_STORE
+                if (t0 != 0xFFFFFFF0u) continue;   // ablation build: what the stores of this path cost
+#endif
                 if (B == 1) *reinterpret_cast<uint32_t *>(q) = d0;
                 else if (B == 2) *reinterpret_cast<Dwords2 *>(q) = Dwords2{d0, d1};
                 else if (B == 3) *reinterpret_cast<Dwords3 *>(q) = Dwords3{d0, d1, d2};
