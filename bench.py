@@ -169,11 +169,20 @@ def main():
     import flac_amd
     import synth
 
+    # FLAC_BENCH_REHEARSE=1: every rank on GPU 0 and gloo for the timing scalars, to run the multi-rank path
+    # on a one-GPU box (RCCL refuses two ranks on one device); never set for a measurement
+    rehearse = bool(os.environ.get("FLAC_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if rehearse else dev
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     rate, channels, bps, blocksize = args.rate, args.channels, args.bps, args.blocksize
     nsamples = int(round(args.seconds * rate))
@@ -290,10 +299,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        vv = torch.tensor([float(values_total), float(pcm_total), float(comp_total)], dtype=torch.float64, device=dev)
+        vv = torch.tensor([float(values_total), float(pcm_total), float(comp_total)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(vv, op=dist.ReduceOp.SUM)
         values_all, pcm_all, comp_all = [float(x) for x in vv.tolist()]
     else:
