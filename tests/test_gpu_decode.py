@@ -75,6 +75,24 @@ def test_synthetic_cases_one_batch(decoder):
         assert r.pcm_bytes == len(src), name
 
 
+@pytest.mark.parametrize("lead", [1, 2, 3])
+def test_odd_input_and_output_addresses(decoder, lead):
+    """Streams packed back to back at arbitrary byte offsets, output regions at odd addresses with no gap
+    between them: the write-out falls back from dword stores to bytes, must produce the same PCM and must not
+    touch a byte outside a stream's region (every shape of the case list, one batch)."""
+    enc = [encode_case(i, c) for i, c in enumerate(CASES)]
+    files = [f for _, f, _ in enc]
+    pcms, res, infos, raw, offs = gpu_batch(decoder, files, pad=1, out_pad=1, in_lead=lead, out_lead=lead, out_fill=0xA5,
+                                           return_raw=True)
+    covered = np.zeros(raw.size, dtype=bool)
+    for (name, f, x), p, r, si, o in zip(enc, pcms, res, infos, offs):
+        want, ost = oracle_decode(si, split_file(f)[1])
+        assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples), name
+        assert np.array_equal(p, want), name
+        covered[o: o + si.pcm_bytes] = True
+    assert np.all(raw[~covered] == 0xA5)
+
+
 def test_host_buffer_entry_point(decoder, testdata):
     """flacgpu_decode_batch (host pointers, PCIe copies inside)."""
     pcm, si, res = flac_amd.decode_file(os.path.join(testdata, STEREO), decoder)

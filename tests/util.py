@@ -37,9 +37,12 @@ def oracle_decode(si, audio):
     return full, st
 
 
-def gpu_batch(decoder, files, pad=64, out_fill=0):
+def gpu_batch(decoder, files, pad=64, out_fill=0, out_pad=64, in_lead=0, out_lead=0, return_raw=False):
     """Decodes whole .flac byte strings with the device-resident entry point.
-    Returns (list of pcm np.uint8 arrays, results, infos)."""
+    pad / out_pad: alignment of every stream's input / output region; in_lead / out_lead: bytes in front
+    of the first one (odd values put everything at odd addresses).
+    Returns (list of pcm np.uint8 arrays, results, infos) and, with return_raw, the whole output buffer
+    and the output offsets."""
     import torch
     infos, audios = [], []
     for f in files:
@@ -47,16 +50,16 @@ def gpu_batch(decoder, files, pad=64, out_fill=0):
         infos.append(si)
         audios.append(a)
     in_offs, out_offs = [], []
-    pos = 0
+    pos = in_lead
     for a in audios:
         in_offs.append(pos)
         pos += (len(a) + pad - 1) // pad * pad
     in_bytes = max(pos, 16)
-    pos = 0
+    pos = out_lead
     for si in infos:
         out_offs.append(pos)
-        pos += (si.pcm_bytes + 63) // 64 * 64
-    out_bytes = max(pos, 64)
+        pos += (si.pcm_bytes + out_pad - 1) // out_pad * out_pad
+    out_bytes = max(pos + out_lead, 64)
     host = np.zeros(in_bytes, dtype=np.uint8)
     for a, o in zip(audios, in_offs):
         host[o:o + len(a)] = np.frombuffer(a, dtype=np.uint8)
@@ -68,6 +71,8 @@ def gpu_batch(decoder, files, pad=64, out_fill=0):
     torch.cuda.synchronize()
     out = d_out.cpu().numpy()
     pcms = [out[out_offs[i]: out_offs[i] + infos[i].pcm_bytes].copy() for i in range(len(files))]
+    if return_raw:
+        return pcms, list(res), infos, out, out_offs
     return pcms, list(res), infos
 
 
