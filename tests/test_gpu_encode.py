@@ -43,6 +43,18 @@ def test_encode_groups_match_oracle(decoder, group):
     _check_against_oracle(files, res, packed, shapes, gopts, oracle.enc_options(**group["opts"]))
 
 
+def test_encode_at_dword_aligned_offsets_only(decoder):
+    """PCM and output regions at offsets that are multiples of 4 and of nothing larger, packed with no gap:
+    the loaders and the packer's whole-word copy-out must not depend on wider alignment."""
+    for group in ENC_GROUPS[:3]:
+        src = make_pcm_group(group)
+        packed = [p for _, p, _ in src]
+        shapes = [s for _, _, s in src]
+        gopts = flac_amd.encode_options(flags=flac_amd.ENC_MD5, **group["opts"])
+        files, res = gpu_encode_group(decoder, packed, shapes, gopts, align=4, lead=4)
+        _check_against_oracle(files, res, packed, shapes, gopts, oracle.enc_options(**group["opts"]))
+
+
 def test_encode_special_signals(decoder):
     """Silence, constants, wasted bits, full-scale noise (verbatim), spikes (long Rice codes), ramps."""
     rng = np.random.default_rng(11)

@@ -96,22 +96,22 @@ def make_pcm_group(group, seed=7):
     return out
 
 
-def gpu_encode_group(engine, packed, shapes, opts, cap_scale=1.0, md5s=None):
+def gpu_encode_group(engine, packed, shapes, opts, cap_scale=1.0, md5s=None, align=256, lead=0):
     """Encodes packed PCM byte strings with the device-resident entry point.
     Returns (list of .flac byte strings or None where the stream did not fit, results)."""
     import torch
     in_offs, out_offs, caps = [], [], []
-    pos = 0
+    pos = lead
     for p in packed:
         in_offs.append(pos)
-        pos += (len(p) + 255) // 256 * 256
+        pos += (len(p) + align - 1) // align * align
     pcm_bytes = pos + 256
-    pos = 0
+    pos = lead
     for (n, rate, ch, bps) in shapes:
         cap = int(flac_amd.encode_bound(n, ch, bps, opts.blocksize, opts.seektable_interval) * cap_scale)
         caps.append(cap)
         out_offs.append(pos)
-        pos += (cap + 255) // 256 * 256
+        pos += (cap + align - 1) // align * align
     out_bytes = pos + 256
     host = np.zeros(pcm_bytes, dtype=np.uint8)
     for p, o in zip(packed, in_offs):
