@@ -93,6 +93,37 @@ def test_odd_input_and_output_addresses(decoder, lead):
     assert np.all(raw[~covered] == 0xA5)
 
 
+def test_thousands_of_small_streams(decoder):
+    """A batch of 4000 streams of one to three short frames each, with empty inputs and inputs that hold
+    no frame at all scattered among them: per-stream candidate ranges, results and output regions must stay
+    apart (checked against the oracle once per distinct stream)."""
+    rng = np.random.default_rng(3)
+    kinds = []
+    for i, (ch, bps, n, bs) in enumerate([(2, 16, 17, 4096), (1, 16, 700, 576), (2, 24, 1200, 1152), (6, 16, 300, 256),
+                                          (2, 16, 4097, 4096), (2, 8, 40, 192)]):
+        x = synth.pcm(900 + i, n, ch, bps, 44100, bs)
+        f, _ = synth.encode(x, bps, 44100, synth.options(bs, 8))
+        kinds.append(bytes(f))
+    si0, _ = split_file(kinds[0])
+    head0 = kinds[0][: len(kinds[0]) - len(split_file(kinds[0])[1])]
+    kinds.append(head0)                                                         # STREAMINFO, no audio bytes at all
+    kinds.append(head0 + bytes(rng.integers(0, 256, size=500).astype(np.uint8)))  # no frame among the bytes
+    pick = rng.integers(0, len(kinds), size=4000)
+    files = [kinds[k] for k in pick]
+    pcms, res, infos = gpu_batch(decoder, files, pad=1, out_fill=0x11)
+    expect = []
+    for f in kinds:
+        si, a = split_file(f)
+        expect.append(oracle_decode(si, a))
+    for k, p, r in zip(pick, pcms, res):
+        want, ost = expect[k]
+        assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples)
+        if ost.frames_ok:
+            assert np.array_equal(p, want)
+        else:
+            assert np.all(p == 0x11)
+
+
 def test_host_buffer_entry_point(decoder, testdata):
     """flacgpu_decode_batch (host pointers, PCIe copies inside)."""
     pcm, si, res = flac_amd.decode_file(os.path.join(testdata, STEREO), decoder)
