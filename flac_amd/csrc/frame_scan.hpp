@@ -448,13 +448,12 @@ __device__ inline void crc16_pow_table(uint16_t *pow2)
 }
 
 // Lookup tables of k_crc16_spans, built once per handle (uint16 entries):
-//   piece[m][v]  (16 x 256)  v * x^(16 + 8m): byte v with m more bytes behind it in its 16-byte piece
 //   skip[h][v]   (2 x 256)   multiplication of a 16-bit remainder by x^(8 * 1024), split by byte
 //   lanew[l]     (64)        x^(8 * 16 * (63 - l))
 //   remw[r]      (16)        x^(8 * r)
 //   pow2[k]      (32)        x^(8 * 2^k), for gf_xpow8
 //   inv[r]       (16)        x^(-8 * r): x has order 32767 modulo 0x18005 = (x + 1)(x^15 + x + 1)
-constexpr int kCrcPiece = 0, kCrcSkip = 16 * 256, kCrcLane = kCrcSkip + 512, kCrcRem = kCrcLane + 64,
+constexpr int kCrcSkip = 0, kCrcLane = kCrcSkip + 512, kCrcRem = kCrcLane + 64,
               kCrcPow2 = kCrcRem + 16, kCrcInv = kCrcPow2 + 32, kCrcTableEntries = kCrcInv + 16;
 
 __global__ void k_crc16_build_tables(uint16_t *t)
@@ -464,10 +463,7 @@ __global__ void k_crc16_build_tables(uint16_t *t)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries; i += blockDim.x) {
         uint32_t v;
-        if (i < (uint32_t)kCrcSkip) {
-            const uint32_t m = i >> 8, byte = i & 255;
-            v = gf_mulmod(byte, gf_xpow8(2 + m, s_pow2));             // byte * x^(16 + 8m)
-        } else if (i < (uint32_t)kCrcLane) {
+        if (i < (uint32_t)kCrcLane) {
             const uint32_t hsel = (i - kCrcSkip) >> 8, byte = i & 255;
             v = gf_mulmod(hsel ? byte << 8 : byte, gf_xpow8(1024, s_pow2));
         } else if (i < (uint32_t)kCrcRem) {
@@ -483,25 +479,38 @@ __global__ void k_crc16_build_tables(uint16_t *t)
     }
 }
 
-// CRC-16 of the 16 bytes of a vector taken as a message of its own (init 0): sixteen independent lookups.
-__device__ inline uint32_t crc16_piece(const uint4 v, const uint16_t *piece)
+// CRC-16 of the 16 bytes of a vector taken as a message of its own (init 0), without tables: byte-table
+// lookups from 64 lanes collide in the LDS banks and made the kernel LDS-bound.
+// The polynomial factors: x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1).  Modulo x + 1 a polynomial is the
+// parity of its bits.  Modulo Q = x^15 + x + 1, x^15 = x + 1, so a high part h (bits 15 and up) folds down as
+// h + h*x; x^32 = x^4 + x^2, x^64 = x^8 + x^4, x^96 = x^12 + x^10 + x^8 + x^6 and x^16 = x^2 + x.  The
+// remainder r modulo Q and the parity p of the message give the CRC as r + c*Q with c = p + parity(r)
+// (Q has three terms, so adding it flips the parity).
+__device__ inline uint32_t crc16_fold15(uint32_t w)   // congruent to w modulo Q; below 2^18 for any w, below 2^15 for w < 2^19
 {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t c = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
-        c ^= piece[(15 - k) * 256 + byte];
-    }
-    return c;
+    const uint32_t h = w >> 15;
+    return (w & 0x7FFFu) ^ h ^ (h << 1);
+}
+__device__ inline uint32_t crc16_piece(const uint4 v)
+{
+    const uint32_t parity = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    // the message's four words, first byte in the highest bits
+    const uint32_t a = crc16_fold15(__builtin_bswap32(v.x)), b = crc16_fold15(__builtin_bswap32(v.y)),
+                   c = crc16_fold15(__builtin_bswap32(v.z)), d = crc16_fold15(__builtin_bswap32(v.w));
+    uint32_t t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d;   // < 2^30
+    t = crc16_fold15(t);             // < 2^17
+    t = (t << 2) ^ (t << 1);         // times x^16: the CRC is the remainder of message * x^16
+    t = crc16_fold15(t);             // < 2^15: the remainder modulo Q
+    const uint32_t flip = (parity + __popc(t)) & 1u;
+    return t ^ (0x8003u & (0u - flip));
 }
 
 // CRC-16 of every candidate span [goff[r], goff[r] + seglen[r]).  One wave per span at a time (waves
 // stride over the spans).  The span is cut into 16-byte pieces on 16-byte boundaries; the bytes of the
 // first piece before the span and of the last piece after it are taken as zeros (leading zeros do not
 // change a CRC that starts from zero; trailing zeros multiply it by a known power of x, divided out at
-// the end).  Lanes load consecutive pieces (1 KiB per wave per step), reduce each to its remainder with
-// sixteen table lookups, and carry it over the 1 KiB stride by a table multiplication; at the end the 64
+// the end).  Lanes load consecutive pieces (1 KiB per wave per step), reduce each to its remainder
+// (crc16_piece), and carry it over the 1 KiB stride by a table multiplication; at the end the 64
 // partial remainders are weighted by lane and XOR-ed.  The next step's piece (or the first piece of the
 // wave's next span) is loaded before the current one is processed.
 __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__ in, CandArrays c, uint32_t n_cand,
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries / 2; i += blockDim.x)
         reinterpret_cast<uint32_t *>(s_t)[i] = reinterpret_cast<const uint32_t *>(tables)[i];
     __syncthreads();
-    const uint16_t *piece = s_t + kCrcPiece, *skip = s_t + kCrcSkip;
+    const uint16_t *skip = s_t + kCrcSkip;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t lanew = s_t[kCrcLane + lane];
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
             const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)g.pad;
             if (t == 0 && g.lead && j == 0) cur = keep_bytes(cur, g.lead, 16);
             if (t + 1 == g.steps && g.trail && j == (int32_t)g.npieces - 1) cur = keep_bytes(cur, 0, 16 - g.trail);
-            const uint32_t pc = crc16_piece(cur, piece);
+            const uint32_t pc = crc16_piece(cur);
             acc = skip[acc & 0xFF] ^ skip[256 + (acc >> 8)] ^ pc;
             cur = nxt;
         }
