@@ -53,9 +53,10 @@ constexpr uint32_t kFetchBelow = kRingWords >= 32 ? 17 : kRingWords - kUnitWords
 #endif
 constexpr uint32_t kSkimPairK = FLACGPU_SKIM_PAIR_K;
 
-// a * b + c on the low 24 bits of a and b (sign-extended), low 32 bits of the result: one full-rate
-// instruction where a 32-bit multiply takes four.  Exact whenever a and b fit 24 bits.  Written as
-// asm because the compiler only selects it when it can see both sign-extensions in the same block.
+// a * b + c on the low 24 bits of a and b (sign-extended), low 32 bits of the result: one instruction
+// where a 32-bit multiply and an add are two (both multiplies issue at the full rate on gfx950).  Exact
+// whenever a and b fit 24 bits.  Written as asm because the compiler only selects it when it can see
+// both sign-extensions in the same block.
 __device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
 {
     int32_t r;
