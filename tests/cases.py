@@ -36,6 +36,10 @@ CASES = [
     dict(name="6ch16", channels=6, bps=16, n=7000, bs=1152, rate=48000),
     dict(name="stereo8", channels=2, bps=8, n=5000, bs=512),
     dict(name="mono32", channels=1, bps=32, n=3000, bs=512),
+    dict(name="bs65535", channels=2, bps=16, n=65535 + 1234, bs=65535),
+    dict(name="bs32768-mono24", channels=1, bps=24, n=32768 + 77, bs=32768),
+    dict(name="bs16", channels=2, bps=16, n=1250, bs=16),
+    dict(name="bs17-3ch8", channels=3, bps=8, n=1250, bs=17),
 ]
 
 
