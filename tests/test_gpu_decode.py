@@ -124,6 +124,47 @@ def test_thousands_of_small_streams(decoder):
             assert np.all(p == 0x11)
 
 
+def test_unknown_total_and_short_capacity(decoder):
+    """STREAMINFO.TotalSamples == 0 means unknown (flacmeta.go:662 only stores the field): every frame
+    that fits the caller's capacity is decoded.  A capacity that ends inside the stream turns the frames
+    beyond it into range errors and leaves the bytes behind the capacity alone.  Both against the oracle."""
+    import copy
+    import torch
+    enc = [encode_case(i, c) for i, c in enumerate(CASES[:3])]
+    entries, wants, pos_in, pos_out = [], [], 0, 0
+    blobs = []
+    for name, f, x in enc:
+        si, a = split_file(f)
+        full = si.pcm_bytes
+        for total, cap in ((0, full), (si.total_samples, full // 2), (0, full // 3)):
+            si2 = copy.copy(si)
+            si2.total_samples = total
+            pcm, ost = oracle.decode_stream(a, to_oracle_si(si2), pcm_cap=cap)
+            want = np.zeros(cap, dtype=np.uint8)
+            want[: pcm.size] = pcm
+            entries.append((pos_in, len(a), pos_out, cap, si2))
+            wants.append((name, total, cap, want, ost))
+            blobs.append(a)
+            pos_in += (len(a) + 63) // 64 * 64
+            pos_out += (full + 63) // 64 * 64        # room for the whole stream: what lies behind `cap` must stay untouched
+    host = np.zeros(pos_in, dtype=np.uint8)
+    for (o, n, *_), a in zip(entries, blobs):
+        host[o: o + n] = np.frombuffer(a, dtype=np.uint8)
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.full((pos_out,), 0xEE, dtype=torch.uint8, device="cuda")
+    res = decoder.decode_batch_device(d_in, pos_in, d_out, pos_out, decoder.make_streams(entries))
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    ends = [e[2] for e in entries[1:]] + [pos_out]
+    for (o_in, n, o_out, cap, si2), (name, total, cap_, want, ost), r, end in zip(entries, wants, res, ends):
+        what = f"{name} total={total} cap={cap}"
+        assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples), what
+        got = out[o_out: o_out + cap]
+        decoded = int(ost.samples) * si2.channels * ((si2.bits_per_sample + 7) // 8)
+        assert np.array_equal(got[:decoded], want[:decoded]), what
+        assert np.all(out[o_out + cap: end] == 0xEE), what
+
+
 def test_host_buffer_entry_point(decoder, testdata):
     """flacgpu_decode_batch (host pointers, PCIe copies inside)."""
     pcm, si, res = flac_amd.decode_file(os.path.join(testdata, STEREO), decoder)
