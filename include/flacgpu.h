@@ -211,7 +211,8 @@ typedef struct flacgpu_options {
  * device buffer (d_out). */
 typedef struct flacgpu_stream {
     uint64_t in_offset;       /* bytes from d_in to byte 0 of frame 0             */
-    uint64_t in_length;       /* bytes of audio frames                            */
+    uint64_t in_length;       /* bytes of audio frames, below 2 GiB per entry (a longer stream is passed as
+                                 several entries cut at SEEKTABLE offsets: frames carry their own numbers) */
     uint64_t out_offset;      /* bytes from d_out to this stream's first sample   */
     uint64_t out_capacity;    /* bytes this stream may write                      */
     flacgpu_streaminfo info;  /* from flacgpu_parse_metadata / Metadata.Read      */

@@ -165,6 +165,48 @@ def test_unknown_total_and_short_capacity(decoder):
         assert np.all(out[o_out + cap: end] == 0xEE), what
 
 
+def test_decode_rejects_bad_batches(decoder, testdata):
+    """Batch descriptions the kernels could not index safely are refused before anything is launched:
+    streams out of order or overlapping, regions beyond either buffer, STREAMINFO fields out of bounds,
+    a misaligned input pointer."""
+    import copy
+    import torch
+    si, a = split_file(_read(testdata, STEREO))
+    n = len(a)
+    host = np.zeros(2 * ((n + 63) // 64 * 64) + 64, dtype=np.uint8)
+    host[:n] = np.frombuffer(a, dtype=np.uint8)
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.zeros(2 * si.pcm_bytes + 64, dtype=torch.uint8, device="cuda")
+    ib, ob = host.size, d_out.numel()
+    ok = (0, n, 0, si.pcm_bytes, si)
+    res = decoder.decode_batch_device(d_in, ib, d_out, ob, decoder.make_streams([ok]))
+    assert res[0].frames_ok == 36
+
+    def bad_info(**kw):
+        s2 = copy.copy(si)
+        for k, v in kw.items():
+            setattr(s2, k, v)
+        return s2
+    second = (n + 63) // 64 * 64
+    for entries in ([(second, n, 0, si.pcm_bytes, si), (0, n, si.pcm_bytes, si.pcm_bytes, si)],      # descending
+                    [(0, n, 0, si.pcm_bytes, si), (n - 1, n, si.pcm_bytes, si.pcm_bytes, si)],        # overlapping inputs
+                    [(ib - 10, n, 0, si.pcm_bytes, si)],                                              # input beyond the buffer
+                    [(0, n, ob - 10, si.pcm_bytes, si)],                                              # output beyond the buffer
+                    [(0, n, 0, si.pcm_bytes, bad_info(channels=0))],
+                    [(0, n, 0, si.pcm_bytes, bad_info(channels=9))],
+                    [(0, n, 0, si.pcm_bytes, bad_info(bits_per_sample=3))],
+                    [(0, n, 0, si.pcm_bytes, bad_info(bits_per_sample=33))],
+                    [(0, n, 0, si.pcm_bytes, bad_info(max_blocksize=15))]):
+        with pytest.raises(flac_amd.FlacError):
+            decoder.decode_batch_device(d_in, ib, d_out, ob, decoder.make_streams(entries))
+    with pytest.raises(flac_amd.FlacError):
+        decoder.decode_batch_device(d_in[4:], ib - 4, d_out, ob, decoder.make_streams([ok]))           # pointer not 16-byte aligned
+    # the handle is still good afterwards
+    res = decoder.decode_batch_device(d_in, ib, d_out, ob, decoder.make_streams([ok]))
+    torch.cuda.synchronize()
+    assert res[0].frames_ok == 36 and md5hex(d_out[: si.pcm_bytes].cpu().numpy()) == si.md5_signature
+
+
 def test_host_buffer_entry_point(decoder, testdata):
     """flacgpu_decode_batch (host pointers, PCIe copies inside)."""
     pcm, si, res = flac_amd.decode_file(os.path.join(testdata, STEREO), decoder)
