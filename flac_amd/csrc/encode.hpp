@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ p
     int type = 2, which = 0;
     uint32_t bits = fixed_bits;
     if (use_lpc && (lpc_bits < fixed_bits || o.force_lpc_order)) { type = 3; which = 1; bits = lpc_bits; }
-    if (verb_bits < bits && !o.force_lpc_order) { type = 1; bits = verb_bits; }
+    if (verb_bits < bits) { type = 1; bits = verb_bits; }   // also under a forced order: the size bound rests on it
     if (t == 0) {
         PlanHead h = {};
         h.bits = bits; h.type = (uint8_t)type; h.wasted = (uint8_t)wasted; h.sb = (uint8_t)sb;

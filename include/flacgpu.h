@@ -309,7 +309,8 @@ typedef struct flacgpu_encode_options {
     uint32_t min_partition_order;  /* Rice partition order range, 0..8; min == max forces it       */
     uint32_t max_partition_order;
     int32_t  stereo_mode;          /* -1 cheapest per frame, 0 left/right, 1 left/side, 2 side/right, 3 mid/side */
-    uint32_t force_lpc_order;      /* 0 = estimate the order per subframe; else exactly this order */
+    uint32_t force_lpc_order;      /* 0 = estimate the order per subframe; else every predicted subframe is LPC of
+                                      exactly this order (constant, and verbatim where smaller, still apply) */
     uint32_t flags;                /* FLACGPU_ENC_*                                                */
     uint32_t seektable_interval;   /* a seek point every this many frames (SEEKTABLE block after STREAMINFO,
                                       SeekpointBlock flacmeta.go:256-260); 0 = no seek table       */

@@ -370,7 +370,7 @@ static void plan_subframe(const orc_enc_opts *o, const int32_t *sig, uint32_t bs
         pl->po = rl.po; pl->method = rl.method; pl->bits = lpc_bits;
         memcpy(pl->k, rl.k, sizeof rl.k);
     }
-    if (verb_bits < pl->bits && !o->force_lpc_order) { pl->type = 1; pl->bits = verb_bits; }
+    if (verb_bits < pl->bits) { pl->type = 1; pl->bits = verb_bits; }   /* also under a forced order */
 }
 
 /* Writes the subframe a plan describes; x: the channel signal before removing wasted bits. */
