@@ -16,7 +16,9 @@ dec = flac_amd.Decoder(0)
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    drawn = [T._draw(rng, seed * 100 + i) for i in range(24)]
+    # every third seed: one layout for all streams, so that waves take frames of several streams
+    layout = [(None, None), (None, None), [(2, 16), (1, 16), (2, 24), (6, 16), (8, 24), (3, 12), (2, 8)][(seed // 3) % 7]][seed % 3]
+    drawn = [T._draw(rng, seed * 100 + i, ch=layout[0], bps=layout[1]) for i in range(24)]
     pcms, res, infos = gpu_batch(dec, [d[0] for d in drawn], out_fill=0x77, pad=int(rng.choice([1, 64])),
                                  out_pad=int(rng.choice([1, 4, 64])), out_lead=int(rng.integers(0, 4)))
     for (f, src, what), p, r, si in zip(drawn, pcms, res, infos):

@@ -38,9 +38,9 @@ def _signal(rng, kind, n, ch, bps, idx, rate, bs):
     return x
 
 
-def _draw(rng, idx):
-    ch = int(rng.choice([1, 2, 2, 2, 3, 4, 6, 8]))
-    bps = int(rng.choice([8, 12, 16, 16, 20, 24, 24]))
+def _draw(rng, idx, ch=None, bps=None):
+    ch = int(rng.choice([1, 2, 2, 2, 3, 4, 6, 8])) if ch is None else ch
+    bps = int(rng.choice([8, 12, 16, 16, 20, 24, 24])) if bps is None else bps
     bs = int(rng.choice([192, 576, 1000, 1152, 2048, 4096, 4608]))
     order = int(rng.choice([0, 4, 8, 12, 12, 20, 32]))
     n = int(rng.integers(1, int(3.6 * bs)))
@@ -61,6 +61,22 @@ def _draw(rng, idx):
     x = _signal(rng, int(rng.integers(0, 5)), n, ch, bps, idx, rate, bs)
     f, _ = synth.encode(x, bps, rate, synth.options(bs, order, **kw))
     return bytes(f), synth.pack_pcm(x, bps), f"#{idx} ch{ch} bps{bps} bs{bs} order{order} n{n} {kw}"
+
+
+@pytest.mark.parametrize("shape", [(2, 16), (1, 16), (2, 24), (6, 16), (8, 24)])
+def test_random_streams_of_one_layout(decoder, shape):
+    """Streams that share channel count and sample size are decoded by the same launches, and a wave takes
+    consecutive frames across stream boundaries: lanes of one wave then differ in block size, predictor
+    order and class, Rice method and signal, and short streams end in the middle of a wave."""
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    drawn = [_draw(rng, 7000 + i, ch=shape[0], bps=shape[1]) for i in range(40)]
+    files = [d[0] for d in drawn]
+    pcms, res, infos = gpu_batch(decoder, files, out_fill=0x77, pad=1)
+    for (f, src, what), p, r, si in zip(drawn, pcms, res, infos):
+        want, ost = oracle_decode(si, split_file(f)[1])
+        assert bytes(want) == src, what
+        assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples), what
+        assert np.array_equal(p, want), what
 
 
 @pytest.mark.parametrize("seed", [101, 202, 303, 404])
