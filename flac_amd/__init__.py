@@ -176,7 +176,7 @@ EXPORTS = [
     "flacgpu_encode_bound", "flacgpu_encode_batch_device", "flacgpu_encode_batch", "flacgpu_get_encode_timing",
     "flacgpu_md5_batch_device", "flacgpu_seektable_bytes",
     "flacgpu_parse_vorbis_comment", "flacgpu_parse_picture", "flacgpu_picture_type_string", "flacgpu_parse_application",
-    "flacgpu_parse_cuesheet",
+    "flacgpu_parse_cuesheet", "flacgpu_skip_id3v2",
 ]
 
 _lib = None
@@ -218,6 +218,7 @@ def lib():
         L.flacgpu_parse_application.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ApplicationHead)]
         L.flacgpu_parse_cuesheet.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(CuesheetHead), ctypes.POINTER(CuesheetTrack), sz,
                                              ctypes.POINTER(CuesheetIndex), sz, ctypes.POINTER(sz)]
+        L.flacgpu_skip_id3v2.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(sz)]
         L.flacgpu_status_string.restype = ctypes.c_char_p
         L.flacgpu_status_string.argtypes = [ctypes.c_int]
         L.flacgpu_create.argtypes = [ctypes.POINTER(Options), ctypes.POINTER(vp)]
@@ -354,6 +355,16 @@ def parse_metadata(buf: bytes) -> Metadata:
     if rc:
         raise FlacError(rc)
     return out
+
+
+def skip_id3v2(buf: bytes) -> int:
+    """Bytes of ID3v2 tag(s) in front of the "fLaC" marker (0 when there is none).  Read itself stays as strict
+    as the reference (flacmeta.go:754-761): pass buf[skip_id3v2(buf):] to parse_metadata to accept tagged files."""
+    off = ctypes.c_size_t()
+    rc = lib().flacgpu_skip_id3v2(bytes(buf), len(buf), ctypes.byref(off))
+    if rc:
+        raise FlacError(rc)
+    return int(off.value)
 
 
 # -------------------------------------------------------------- frame engine
@@ -515,6 +526,16 @@ def decode_file(path_or_bytes, decoder: Decoder = None):
     md = parse_metadata(data)
     if not md.has_streaminfo:
         raise FlacError(6, "no STREAMINFO block")
+    si = md.streaminfo
+    audio = data[md.first_frame_offset:]
+    # the output is sized from STREAMINFO: "0 == Implied Unknown" (flacmeta.go:662) gives nothing to size it from,
+    # and a frame is at least 8 + channels bytes for at most max_blocksize samples
+    if si.total_samples == 0:
+        raise FlacError(11, "TotalSamples is unknown (0): scan the frames and decode with an explicit capacity")
+    if si.total_samples > (len(audio) // (8 + si.channels)) * si.max_blocksize:
+        raise FlacError(6, "STREAMINFO TotalSamples exceeds what the audio bytes can hold")
     dec = decoder or Decoder()
-    outs, res = dec.decode_batch([data[md.first_frame_offset:]], [md.streaminfo])
-    return outs[0], md.streaminfo, res[0]
+    outs, res = dec.decode_batch([audio], [si])
+    if res[0].frames and not res[0].frames_ok:
+        raise FlacError(11, "no frame of the stream decoded")
+    return outs[0], si, res[0]

@@ -218,7 +218,10 @@ int flacgpu_create(const flacgpu_options *opts, flacgpu_handle **out)
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || h->device < 0 || h->device >= count) { delete h; return FLACGPU_ERR_DEVICE; }
     if (hipSetDevice(h->device) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
+    // A blocking stream: work issued to it is ordered after what the caller has already put on the legacy
+    // default stream (stream 0, which is also what torch.cuda.current_stream() is unless the caller changed
+    // it), so a d_in / d_out that stream 0 is still filling is complete before the first kernel reads it.
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return FLACGPU_ERR_DEVICE; }
     if (hipMalloc(&h->crc_tables.p, kCrcTableEntries * 2) != hipSuccess) { flacgpu_destroy(h); return FLACGPU_ERR_NOMEM; }

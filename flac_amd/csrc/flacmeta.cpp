@@ -249,6 +249,28 @@ int flacgpu_parse_metadata(const uint8_t *buf, size_t len, flacgpu_metadata *out
     return FLACGPU_OK;
 }
 
+// Measures the ID3v2 tag(s) in front of the "fLaC" marker.  Not part of Read: the reference
+// refuses such files (flacmeta.go:754-761) and flacgpu_parse_metadata stays as strict.
+int flacgpu_skip_id3v2(const uint8_t *buf, size_t len, size_t *offset)
+{
+    if (!buf || !offset) return FLACGPU_ERR_ARG;
+    size_t pos = 0;
+    *offset = 0;
+    for (;;) {
+        if (len - pos < 10) break;   // no room for another tag header: whatever follows is not a tag
+        const uint8_t *t = buf + pos;
+        if (t[0] != 'I' || t[1] != 'D' || t[2] != '3') break;
+        if (t[3] == 0xFF || t[4] == 0xFF) break;
+        if ((t[6] | t[7] | t[8] | t[9]) & 0x80) break;       // not a sync-safe size: not a tag
+        const size_t body = ((size_t)t[6] << 21) | ((size_t)t[7] << 14) | ((size_t)t[8] << 7) | (size_t)t[9];
+        const size_t total = 10 + body + ((t[5] & 0x10) ? 10 : 0);
+        if (len - pos < total) return FLACGPU_ERR_TRUNCATED;
+        pos += total;
+        *offset = pos;
+    }
+    return FLACGPU_OK;
+}
+
 const char *flacgpu_status_string(int status)
 {
     switch (status) {

@@ -620,7 +620,8 @@ __global__ __launch_bounds__(256) void k_resolve_chain(StreamDev *streams, CandA
     }
     if (found) {
         c.len[r] = total;
-        c.status[r] = range_status(streams[si], c.info[r], c.num[r]);
+        // the subframe kernels count a frame's bits in 32 bits from a 64-byte-aligned base
+        c.status[r] = total >= (1u << 29) - 64 ? kFrameUnsupported : range_status(streams[si], c.info[r], c.num[r]);
         c.next[r] = found;
         if (found != r + 1) streams[si].pending = 1;   // candidates inside this frame have to be struck out
     } else {

@@ -340,6 +340,14 @@ public:
         si.sample_rate = s.SampleRate; si.channels = s.Channels; si.bits_per_sample = s.BitsPerSample;
         si.total_samples = s.TotalSamples;
         for (int i = 0; i < 16; ++i) si.md5[i] = (uint8_t)std::stoi(s.MD5Signature.substr(2 * i, 2), nullptr, 16);
+        // The output is sized from STREAMINFO.  "0 == Implied Unknown" (flacmeta.go:662) leaves nothing to size it
+        // from, and a hostile 36-bit TotalSamples would ask for terabytes: a frame is at least 8 + Channels bytes
+        // (header, one constant subframe per channel, CRC-16) and holds at most MaxBlockSize samples.
+        if (s.TotalSamples == 0)
+            return "DecodeFrames: TotalSamples is unknown (0); scan the frames and decode with an explicit capacity";
+        const uint64_t max_frames = audio.size() / (8u + s.Channels);
+        if (s.TotalSamples > max_frames * (uint64_t)s.MaxBlockSize)
+            return "DecodeFrames: STREAMINFO TotalSamples exceeds what the audio bytes can hold";
         pcm.assign((size_t)(s.TotalSamples * s.Channels * ((s.BitsPerSample + 7) / 8)), 0);
         const uint8_t *in = audio.data();
         const uint64_t len = audio.size(), cap = pcm.size();
@@ -349,6 +357,7 @@ public:
             return std::string("decode: ") + flacgpu_status_string(rc) + ": " + flacgpu_last_error(h_);
         res.HeaderCandidates = r.header_candidates; res.Frames = r.frames; res.FramesOK = r.frames_ok;
         res.Samples = r.samples; res.PCMBytes = r.pcm_bytes;
+        if (r.frames && !r.frames_ok) return "decode: no frame of the stream decoded";
         return "";
     }
 

@@ -130,6 +130,16 @@ int flacgpu_parse_seektable(const uint8_t *b, size_t n, flacgpu_seekpoint *out, 
 /* (*Metadata).Read, flacmeta.go:749-850: marker, block loop, duplicate rules. */
 int flacgpu_parse_metadata(const uint8_t *buf, size_t len, flacgpu_metadata *out);
 
+/* Leading ID3v2 tags.  The reference refuses any file whose first four bytes are not
+ * "fLaC" (flacmeta.go:754-761), and so does flacgpu_parse_metadata; files in the wild often
+ * carry an ID3v2 tag in front of the marker.  This helper only measures it: *offset = bytes
+ * of ID3v2 tag(s) at the start of buf (0 when there is none), so that a caller who wants to
+ * accept such files passes buf + *offset on.  A tag is "ID3", two version bytes (neither
+ * 0xFF), a flags byte, a 28-bit sync-safe size (four bytes below 0x80), the tag body, and
+ * a 10-byte footer when flag 0x10 is set.  FLACGPU_ERR_TRUNCATED when a tag's header is
+ * complete but the buffer ends inside the tag. */
+int flacgpu_skip_id3v2(const uint8_t *buf, size_t len, size_t *offset);
+
 /* The payload parsers below restate the reference's remaining Marshal* functions.  They
  * allocate nothing: strings and blobs are reported as (offset, length) into the payload the
  * caller passed.  A payload too short for its own fields, which makes the reference panic
@@ -258,6 +268,17 @@ typedef struct flacgpu_timing {
     uint64_t out_bytes;
 } flacgpu_timing;
 
+/* Stream ordering (every entry point with a hip_stream argument).  hip_stream is a
+ * hipStream_t; all of the call's kernels and copies run on it, and the call returns when
+ * they are complete.  NULL selects the handle's own stream, a *blocking* stream: its work
+ * is ordered after everything already issued to the legacy default stream (stream 0).
+ * Whatever produces d_in (or still writes d_out) must therefore be on hip_stream, on
+ * stream 0 when hip_stream is NULL, or synchronised by the caller before the call; work on
+ * any other non-blocking stream is not ordered with the library's.
+ *
+ * Readable extent of d_in: the scan, the skim and the decoder load d_in in whole 16-byte
+ * vectors, so d_in must be 16-byte aligned (checked) and readable up to the next multiple
+ * of 16 bytes after in_bytes; the bytes past in_bytes are never interpreted. */
 int  flacgpu_create(const flacgpu_options *opts, flacgpu_handle **out);
 void flacgpu_destroy(flacgpu_handle *h);
 const char *flacgpu_last_error(const flacgpu_handle *h);

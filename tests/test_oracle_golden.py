@@ -131,6 +131,64 @@ def test_metadata_error_behaviour():
     assert (hdr.type, hdr.length, hdr.last) == (5, 57, 1)
 
 
+def _id3v2(body_len, footer=False, version=(4, 0)):
+    size = bytes([(body_len >> 21) & 0x7F, (body_len >> 14) & 0x7F, (body_len >> 7) & 0x7F, body_len & 0x7F])
+    tag = b"ID3" + bytes(version) + bytes([0x10 if footer else 0]) + size + bytes(range(256)) * (body_len // 256 + 1)
+    tag = tag[:10 + body_len]
+    if footer:
+        tag += b"3DI" + bytes(version) + bytes([0x10]) + size
+    return tag
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_leading_id3v2_tag_is_measured_and_read_stays_strict(name):
+    """A tagged file is refused by Read, as the reference refuses it (flacmeta.go:754-761); behind the
+    measured tag the parse equals the untagged file's."""
+    good = _data(name)
+    want = flac_amd.parse_metadata(good)
+    assert flac_amd.skip_id3v2(good) == 0
+    for tags in ([_id3v2(0)], [_id3v2(300)], [_id3v2(70000, footer=True)], [_id3v2(5, version=(3, 0)), _id3v2(129)]):
+        lead = b"".join(tags)
+        tagged = lead + good
+        with pytest.raises(flac_amd.FlacError) as e:
+            flac_amd.parse_metadata(tagged)
+        assert e.value.status == 2
+        off = flac_amd.skip_id3v2(tagged)
+        assert off == len(lead)
+        got = flac_amd.parse_metadata(tagged[off:])
+        assert bytes(got) == bytes(want)
+
+
+def test_id3v2_edge_cases():
+    assert flac_amd.skip_id3v2(b"") == 0
+    assert flac_amd.skip_id3v2(b"ID3") == 0                                   # too short to be a tag header
+    assert flac_amd.skip_id3v2(b"ID3\x04\x00\x00\x00\x00\x00\x80" + b"x" * 200) == 0   # size byte with the top bit set: not a tag
+    assert flac_amd.skip_id3v2(b"ID3\xff\x00\x00\x00\x00\x00\x01" + b"x" * 200) == 0   # version byte 0xFF: not a tag
+    with pytest.raises(flac_amd.FlacError) as e:
+        flac_amd.skip_id3v2(_id3v2(100)[:60])                                 # buffer ends inside the tag
+    assert e.value.status == 5
+    with pytest.raises(flac_amd.FlacError) as e:
+        flac_amd.skip_id3v2(_id3v2(100, footer=True)[:115])                   # ... inside the footer
+    assert e.value.status == 5
+
+
+def test_min_framesize_where_the_reference_leaks_a_byte():
+    """flacmeta.go:699 computes MinFrameSize as uint32(bits >> 24) of a word that holds MaxBlockSize above it,
+    so the low byte of MaxBlockSize lands in bits 24-31 of the reference's MinFrameSize.  The restatement masks
+    the field to its 24 bits (the format's value); the two agree whenever MaxBlockSize % 256 == 0, which is all
+    the reference's tests cover (4096, 4608).  With MaxBlockSize 1152 (0x480) they differ, on purpose."""
+    si = bytearray(_data(FIXTURES[0])[8:42])
+    si[0:2] = (1152).to_bytes(2, "big")
+    si[2:4] = (1152).to_bytes(2, "big")
+    si[4:7] = (11).to_bytes(3, "big")
+    got = flac_amd.parse_streaminfo(bytes(si))
+    assert (got.min_blocksize, got.max_blocksize, got.min_framesize) == (1152, 1152, 11)
+    bits = int.from_bytes(si[2:10], "big")                 # MaxBlockSize | MinFrameSize | MaxFrameSize
+    reference_value = (bits >> 24) & 0xFFFFFFFF
+    assert reference_value == (0x80 << 24) | 11 and reference_value != got.min_framesize
+    assert bytes(oracle.parse_streaminfo(bytes(si))) == bytes(got)
+
+
 def test_abi_exports_every_declared_symbol():
     """The shared library loads and exports every function include/flacgpu.h declares."""
     header = open(os.path.join(ROOT, "include", "flacgpu.h")).read()
