@@ -138,9 +138,95 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kernel_ms[dom]}}
 
 
-def main():
+# Named workloads.  cfg3 is the configuration the metric is quoted on (the argparse defaults); cfg4 is the
+# 24-bit / 192 kHz / 8-channel one: every subframe LPC of order 32 with Rice partition order 8, which forces
+# block size 16384 (a first partition of bs / 256 - 32 samples must not be negative), as S files of T seconds
+# (>= 8 GB of PCM per GPU) rather than one hour-long stream cut by range_shards: frames are self-contained, so
+# the kernels see the same work either way.
+PRESETS = {
+    "cfg3": {},
+    "cfg4": dict(rate=192000, channels=8, bps=24, blocksize=16384, lpc_order=32, force_lpc_order=32,
+                 partition_order=8, force_partition_order=8, files=512, unique=16, seconds=20.0, cpu_files=4),
+}
+
+
+def launch_command(gpus, argv, port):
+    """The command that starts one rank per GPU of this node (what the driver itself runs for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child, before anything here
+    touches a GPU, and leave with the child's status.  Refuses when the node has fewer than N devices."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()       # counts devices without initialising one
+    if have < args.gpus and not os.environ.get("FLAC_BENCH_REHEARSE"):
+        print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s); not measurable here", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = launch_command(args.gpus, argv, port)
+    log("starting", args.gpus, "ranks:", " ".join(cmd))
+    sys.exit(subprocess.call(cmd))
+
+
+def workload_tag(args):
+    """Names the stream shape a counter profile was taken on (stored in profiles/*pmc_traffic*.json)."""
+    return (f"{args.rate}Hz_{args.bps}bit_{args.channels}ch_bs{args.blocksize}_lpc{args.lpc_order}_force{args.force_lpc_order}"
+            f"_po{args.partition_order}_fpo{args.force_partition_order}_{args.seconds:g}s")
+
+
+def dominant_decode_kernel(classes, channels, bytes_ps):
+    """Name of the k_decode instantiation the batch ran in, from the class mask the library reports (bit
+    (taps == 32) + 2 * arithmetic); with several classes the widest is named (it is the slowest per sample)."""
+    if not classes:
+        return "k_decode"
+    b = max(i for i in range(6) if classes >> i & 1)
+    return f"k_decode<{32 if b & 1 else 12}, {b >> 1}, {'true' if channels == 2 and bytes_ps == 2 else 'false'}>"
+
+
+def lookup_traffic(tag, kernel, nfiles):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            if pmc.get("workload_tag") != tag or kernel not in pmc["kernels"]:
+                continue
+            kd = pmc["kernels"][kernel]
+            traffic = (2.0 * kd["FETCH_SIZE_KiB"] + kd["WRITE_SIZE_KiB"]) * 1024.0 * nfiles / pmc["files"]
+            return traffic, (f"(2 x FETCH_SIZE + WRITE_SIZE) of {kernel} from {os.path.relpath(path, ROOT)}, measured at "
+                             f"{pmc['files']} files of this workload and scaled to {nfiles}; the factor 2 is calibrated for "
+                             f"coalesced reads only and is an upper bound for this kernel's 32-byte sector reads")
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, f"no committed counter profile of {kernel} on workload {tag}"
+
+
+def host_description():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = None
+    return {"cpu_model": model, "cpu_count": os.cpu_count(), "cpus_usable": usable}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(PRESETS), default="cfg3", help="named workload; explicit options override it")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--files", type=int, default=10000)
@@ -159,11 +245,18 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU sample is decoded repeatedly for about this long")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
     ap.add_argument("--encode-steps", type=int, default=2, help="timed steps of the encode leg (0 = skip it)")
-    args = ap.parse_args()
+    pre = ap.parse_known_args(argv)[0]
+    ap.set_defaults(**PRESETS[pre.config])
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import flac_amd
@@ -298,8 +391,13 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]     # a straggler shows here
+        tt = mine.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         vv = torch.tensor([float(values_total), float(pcm_total), float(comp_total)], dtype=torch.float64, device=red_dev)
@@ -346,6 +444,7 @@ def main():
         got = d_out[:pcm_bytes_per_file].cpu().numpy()
         assert np.array_equal(got, pcm[:pcm_bytes_per_file]), "GPU PCM differs from the CPU oracle"
         cpu = {"value": passes * ncpu * nsamples * channels / cpu_s, "unit": "samples/s", "cores": threads, "kind": "port",
+               "threads": threads, "host_cpu_count": os.cpu_count(),
                "sample": f"{ncpu} of the {unique} unique files ({ncpu * pcm_bytes_per_file / 1e6:.0f} MB PCM) decoded {passes} times, "
                          f"oracle/flac_oracle.c, {threads} threads, {cpu_s:.2f} s"}
 
@@ -355,17 +454,15 @@ def main():
         dec_s = kernel_ms["decode_ms"] / 1e3
         achieved = alg_bytes / dec_s / 1e9 if dec_s > 0 else 0.0
         # HBM traffic of the dominant kernel: counters cannot be read from inside this process, so the figure
-        # comes from the committed rocprofv3 --pmc passes over this same command (profiles/), scaled by files
-        traffic, traffic_note = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_g_pmc_traffic.json")))
-            kd = pmc["kernels"]["k_decode<12, 0, true>"]
-            traffic = (2.0 * kd["FETCH_SIZE_KiB"] + kd["WRITE_SIZE_KiB"]) * 1024.0 * nfiles / pmc["files"]
-            traffic_note = (f"(2 x FETCH_SIZE + WRITE_SIZE) of k_decode from profiles/r1_g_pmc_traffic.json, measured at "
-                            f"{pmc['files']} files and scaled to {nfiles}; the factor 2 is calibrated for coalesced reads "
-                            f"only and is an upper bound for this kernel's 32-byte sector reads")
-        except (OSError, KeyError, ValueError):
-            pass
+        # comes from a committed rocprofv3 --pmc profile (profiles/*pmc_traffic*.json) of this same workload and
+        # this same kernel instantiation, scaled by file count; none that matches -> null
+        dominant = dominant_decode_kernel(dec.timing().decode_classes, channels, bytes_ps)
+        traffic, traffic_note = lookup_traffic(workload_tag(args), dominant, nfiles)
+        prop = torch.cuda.get_device_properties(dev)
+        device = {"name": prop.name, "arch": getattr(prop, "gcnArchName", None), "compute_units": prop.multi_processor_count,
+                  "hbm_GB": prop.total_memory / 1e9, "clock_MHz": getattr(prop, "clock_rate", 0) / 1e3 or None,
+                  "l2_MB": getattr(prop, "L2_cache_size", 0) / 1e6 or None}
+        tot_s = kernel_ms["total_ms"] / 1e3
         out = {
             "metric": "decoded PCM samples/sec",
             "value": values_all * args.steps / elapsed,
@@ -380,6 +477,7 @@ def main():
             "dtype": "int32" if bps <= 16 else "int64",
             "data": "synthetic",
             "config": {
+                "name": args.config, "workload_tag": workload_tag(args),
                 "workload": f"{nfiles} x {args.seconds:g} s {rate / 1000:g} kHz {bps}-bit {channels}-channel FLAC, blocksize {blocksize}, "
                             f"fixed+LPC(<={args.lpc_order})" + (f" forced order {args.force_lpc_order}" if args.force_lpc_order else "")
                             + (f", Rice partition order {args.force_partition_order}" if args.force_partition_order >= 0 else "")
@@ -390,9 +488,14 @@ def main():
             "pcm_MB_per_s": pcm_all * args.steps / elapsed / 1e6,
             "algorithmic_GB_per_s": (pcm_all + comp_all) * args.steps / elapsed / 1e9,
             "kernel_ms": kernel_ms,
-            "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "rank_ms_per_step": rank_ms,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms["decode_ms"]},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms["decode_ms"],
+                         # every kernel of the batch (scan .. results) against the same algorithmic bytes
+                         "pipeline_frac": alg_bytes / tot_s / 8e12 if tot_s > 0 else 0.0, "pipeline_ms": kernel_ms["total_ms"]},
+            "device": device,
+            "host": host_description(),
             "cpu_baseline": cpu,
             "md5_verified": md5_check,
             "encode": enc,

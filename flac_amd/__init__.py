@@ -127,7 +127,8 @@ class Timing(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_float), ("compact_ms", ctypes.c_float), ("crc16_ms", ctypes.c_float),
                 ("resolve_ms", ctypes.c_float), ("skim_ms", ctypes.c_float), ("decode_ms", ctypes.c_float),
                 ("results_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("candidates", ctypes.c_uint64),
-                ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64)]
+                ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64), ("decode_classes", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -177,6 +178,7 @@ EXPORTS = [
     "flacgpu_md5_batch_device", "flacgpu_seektable_bytes",
     "flacgpu_parse_vorbis_comment", "flacgpu_parse_picture", "flacgpu_picture_type_string", "flacgpu_parse_application",
     "flacgpu_parse_cuesheet", "flacgpu_skip_id3v2",
+    "flacgpu_decode_batch_device_noalloc", "flacgpu_noalloc_last_error",
 ]
 
 _lib = None
@@ -230,6 +232,10 @@ def lib():
                                           ctypes.POINTER(u64), ctypes.POINTER(StreamResult), vp]
         L.flacgpu_decode_batch_device.argtypes = [vp, vp, u64, vp, u64, ctypes.POINTER(Stream), u32,
                                                   ctypes.POINTER(StreamResult), vp]
+        L.flacgpu_decode_batch_device_noalloc.argtypes = [ctypes.c_int, vp, u64, vp, u64, ctypes.POINTER(Stream), u32,
+                                                          ctypes.POINTER(StreamResult), vp]
+        L.flacgpu_noalloc_last_error.restype = ctypes.c_char_p
+        L.flacgpu_noalloc_last_error.argtypes = [ctypes.c_int]
         L.flacgpu_decode_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(StreamInfo),
                                            u32, ctypes.POINTER(vp), ctypes.POINTER(u64),
                                            ctypes.POINTER(StreamResult)]
@@ -372,6 +378,21 @@ def skip_id3v2(buf: bytes) -> int:
 def _ptr(t):
     """Device pointer of a torch tensor or a raw int."""
     return t if isinstance(t, int) else t.data_ptr()
+
+
+NOALLOC_MAX_IN_BYTES, NOALLOC_MAX_STREAMS, NOALLOC_MAX_CANDIDATES = 4 << 20, 256, 32768
+
+
+def decode_batch_device_noalloc(device, d_in, in_bytes, d_out, out_bytes, streams, hip_stream=0, results=None):
+    """flacgpu_decode_batch_device_noalloc: the device-resident decode out of the library's static workspace
+    (no handle, no device allocation); small batches only, see the limits above."""
+    n = len(streams)
+    res = results if results is not None else (StreamResult * n)()
+    rc = lib().flacgpu_decode_batch_device_noalloc(int(device), _ptr(d_in), in_bytes, _ptr(d_out), out_bytes, streams, n,
+                                                   res, hip_stream or None)
+    if rc:
+        raise FlacError(rc, lib().flacgpu_noalloc_last_error(int(device)).decode())
+    return res
 
 
 class Decoder:

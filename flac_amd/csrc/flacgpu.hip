@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,7 @@ CandArrays cand_arrays(flacgpu_handle *h)
 int reserve_candidates(flacgpu_handle *h, uint32_t n)
 {
     if (n <= h->cand_cap) return FLACGPU_OK;
+    if (h->fixed) return fail(h, FLACGPU_ERR_CAPACITY, "more frame header candidates than FLACGPU_NOALLOC_MAX_CANDIDATES");
     const size_t cap = (size_t)n + n / 8 + 64;
     int rc;
     if ((rc = reserve(h, h->goff, cap * 8))) return rc;
@@ -153,7 +155,8 @@ int fetch_results(flacgpu_handle *h, uint32_t n, flacgpu_stream_result *results,
 {
     k_results<<<(n + 3) / 4, 256, 0, st>>>((const StreamDev *)h->streams.p, n, cand_arrays(h), (ResultDev *)h->results.p);
     mark(h, EV_RESULTS, st);
-    std::vector<ResultDev> tmp(n);
+    std::vector<ResultDev> &tmp = h->h_results;
+    tmp.resize(n);
     HIP_TRY(hipMemcpyAsync(tmp.data(), h->results.p, (size_t)n * sizeof(ResultDev), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -315,14 +318,10 @@ int flacgpu_scan_frames(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, 
     return ret;
 }
 
-int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, void *d_out, uint64_t out_bytes,
-                                const flacgpu_stream *streams, uint32_t n_streams, flacgpu_stream_result *results,
-                                void *hip_stream)
+// The body of both device-resident decode entry points; `st` is the stream everything runs on.
+static int decode_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, void *d_out, uint64_t out_bytes,
+                         const flacgpu_stream *streams, uint32_t n_streams, flacgpu_stream_result *results, hipStream_t st)
 {
-    if (!h || !d_in || !d_out || !streams || !n_streams) return fail(h, FLACGPU_ERR_ARG, "null argument");
-    if ((uintptr_t)d_in & 15) return fail(h, FLACGPU_ERR_ARG, "d_in must be 16-byte aligned");
-    HIP_TRY(hipSetDevice(h->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     int rc = build_streams(h, in_bytes, out_bytes, streams, n_streams, true);
     if (rc) return rc;
     if ((rc = run_scan(h, (const uint8_t *)d_in, in_bytes, n_streams, st))) return rc;
@@ -340,6 +339,7 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
     }
     CandArrays c = cand_arrays(h);
     const uint64_t in_vecs = (in_bytes + 15) / 16;
+    if (h->flags & FLACGPU_FLAG_TIMING) HIP_TRY(hipMemsetAsync((uint32_t *)h->counter.p + 12, 0, 4, st));
     for (const Run &r : runs) {
         const uint32_t nf = r.r_end - r.r_begin;
         k_skim<<<(nf + 255) / 256, 256, 0, st>>>((const uint8_t *)d_in, in_vecs, c, r.r_begin, r.r_end, r.C,
@@ -370,11 +370,144 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
             FLACGPU_LAUNCH(32, 1, false); FLACGPU_LAUNCH(12, 2, false); FLACGPU_LAUNCH(32, 2, false);
         }
 #undef FLACGPU_LAUNCH
+        if (h->flags & FLACGPU_FLAG_TIMING) k_or_class_flags<<<1, 64, 0, st>>>(p.class_flags, (uint32_t *)h->counter.p + 12);
     }
     mark(h, EV_DECODE, st);
+    uint32_t classes = 0;
+    if (h->flags & FLACGPU_FLAG_TIMING)
+        HIP_TRY(hipMemcpyAsync(&classes, (uint32_t *)h->counter.p + 12, 4, hipMemcpyDeviceToHost, st));
     if ((rc = fetch_results(h, n_streams, results, st))) return rc;
     collect_timing(h, in_bytes, out_bytes);
+    h->timing.decode_classes = classes;
     return FLACGPU_OK;
+}
+
+int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, void *d_out, uint64_t out_bytes,
+                                const flacgpu_stream *streams, uint32_t n_streams, flacgpu_stream_result *results,
+                                void *hip_stream)
+{
+    if (!h || !d_in || !d_out || !streams || !n_streams) return fail(h, FLACGPU_ERR_ARG, "null argument");
+    if ((uintptr_t)d_in & 15) return fail(h, FLACGPU_ERR_ARG, "d_in must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    return decode_device(h, d_in, in_bytes, d_out, out_bytes, streams, n_streams, results,
+                         hip_stream ? (hipStream_t)hip_stream : h->own_stream);
+}
+
+// ---- the entry point that allocates nothing ---------------------------------------------------------
+//
+// Its workspace is a file-scope device array.  Every GPU the library runs on holds its own copy at its
+// own address until the process ends; `scratch` below is only the host-side name of the symbol, never an
+// address a kernel may be given: the per-device address comes from hipGetSymbolAddress, once per device,
+// and everything after that uses that pointer.
+namespace {
+
+constexpr size_t kNaMaxIn = FLACGPU_NOALLOC_MAX_IN_BYTES;
+constexpr size_t kNaMaxStreams = FLACGPU_NOALLOC_MAX_STREAMS;
+constexpr size_t kNaMaxCand = FLACGPU_NOALLOC_MAX_CANDIDATES;
+constexpr size_t kNaTiles = (kNaMaxIn + kScanTileBytes - 1) / kScanTileBytes;
+constexpr size_t na_round(size_t n) { return (n + 255) & ~(size_t)255; }
+// sizes of the pieces, in carving order (each a multiple of 256 bytes)
+constexpr size_t kNaSizes[] = {
+    na_round(kNaMaxStreams * sizeof(StreamDev)),      // streams
+    na_round(kNaMaxStreams * sizeof(ResultDev)),      // results
+    na_round(kNaTiles * kTileGranules * 2),           // mask
+    na_round(kNaTiles * kTileChunks * 8),             // bitmap
+    na_round(kNaTiles * 4),                           // tile_count
+    na_round(kNaTiles * 4),                           // tile_base
+    na_round(((kNaTiles + kPrefixGroup - 1) / kPrefixGroup) * 4),   // group_sum
+    na_round(((kNaTiles + kPrefixGroup - 1) / kPrefixGroup) * 4),   // group_base
+    na_round(64),                                     // counter
+    na_round(kCrcTableEntries * 2),                   // crc_tables
+    na_round(kNaMaxCand * 8), na_round(kNaMaxCand * 8), na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 4),   // goff num info stream
+    na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 2), na_round(kNaMaxCand * 4),   // len status segcrc seglen
+    na_round(kNaMaxCand * 8 * 4), na_round(kNaMaxCand * 4),                                                  // subpos next
+};
+constexpr size_t na_total()
+{
+    size_t t = 0;
+    for (size_t x : kNaSizes) t += x;
+    return t;
+}
+constexpr size_t kNaBytes = na_total();
+static_assert(kNaBytes <= (4u << 20), "the static workspace is meant to stay modest");
+
+}  // namespace
+
+static __device__ __align__(256) uint8_t scratch[kNaBytes];
+
+namespace {
+
+constexpr int kNaMaxDevices = 64;
+struct NoAllocState {
+    flacgpu_handle h;
+    uint8_t *ptr = nullptr;   // this device's copy of `scratch`
+    bool ready = false;
+};
+NoAllocState g_na[kNaMaxDevices];
+std::mutex g_na_mutex;
+thread_local std::string g_na_error;
+
+// Once per device, with that device current: the array's address there, the handle's buffers carved out of
+// it, host vectors at their final size, CRC tables built.
+int noalloc_setup(NoAllocState &s, int device, hipStream_t st)
+{
+    flacgpu_handle *h = &s.h;
+    h->device = device;
+    h->flags = 0;
+    h->fixed = true;
+    uint8_t *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) return fail(h, FLACGPU_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    s.ptr = ptr;
+    DevBuf *bufs[] = {&h->streams, &h->results, &h->mask, &h->bitmap, &h->tile_count, &h->tile_base, &h->group_sum, &h->group_base,
+                      &h->counter, &h->crc_tables, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
+                      &h->seglen, &h->subpos, &h->next};
+    static_assert(sizeof bufs / sizeof bufs[0] == sizeof kNaSizes / sizeof kNaSizes[0], "one size per buffer");
+    size_t off = 0;
+    for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; ++i) {
+        bufs[i]->p = s.ptr + off;
+        bufs[i]->bytes = kNaSizes[i];
+        off += kNaSizes[i];
+    }
+    h->cand_cap = (uint32_t)kNaMaxCand;
+    h->h_streams.reserve(kNaMaxStreams);
+    h->h_results.reserve(kNaMaxStreams);
+    k_crc16_build_tables<<<1, 256, 0, st>>>((uint16_t *)h->crc_tables.p);
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    s.ready = true;
+    return FLACGPU_OK;
+}
+
+}  // namespace
+
+int flacgpu_decode_batch_device_noalloc(int device, const void *d_in, uint64_t in_bytes, void *d_out, uint64_t out_bytes,
+                                        const flacgpu_stream *streams, uint32_t n_streams, flacgpu_stream_result *results,
+                                        void *hip_stream)
+{
+    if (device < 0 || device >= kNaMaxDevices) { g_na_error = "device ordinal out of range"; return FLACGPU_ERR_DEVICE; }
+    NoAllocState &s = g_na[device];
+    flacgpu_handle *h = &s.h;
+    if (!d_in || !d_out || !streams || !n_streams) return fail(h, FLACGPU_ERR_ARG, "null argument");
+    if ((uintptr_t)d_in & 15) return fail(h, FLACGPU_ERR_ARG, "d_in must be 16-byte aligned");
+    if (in_bytes > kNaMaxIn) return fail(h, FLACGPU_ERR_CAPACITY, "in_bytes exceeds FLACGPU_NOALLOC_MAX_IN_BYTES");
+    if (n_streams > kNaMaxStreams) return fail(h, FLACGPU_ERR_CAPACITY, "n_streams exceeds FLACGPU_NOALLOC_MAX_STREAMS");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;   // NULL: the legacy default stream
+    {
+        std::lock_guard<std::mutex> lock(g_na_mutex);
+        if (!s.ready) {
+            int rc = noalloc_setup(s, device, st);
+            if (rc) return rc;
+        }
+    }
+    return decode_device(h, d_in, in_bytes, d_out, out_bytes, streams, n_streams, results, st);
+}
+
+const char *flacgpu_noalloc_last_error(int device)
+{
+    if (device < 0 || device >= kNaMaxDevices) return g_na_error.c_str();
+    return g_na[device].h.err.c_str();
 }
 
 int flacgpu_decode_batch(flacgpu_handle *h, const uint8_t *const *bufs, const uint64_t *lens,

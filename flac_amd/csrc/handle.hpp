@@ -35,6 +35,8 @@ struct flacgpu_handle {
     hipEvent_t ev[flacgpu::EV_COUNT] = {};
     flacgpu_timing timing = {};
     std::vector<flacgpu::StreamDev> h_streams;
+    std::vector<flacgpu::ResultDev> h_results;
+    bool fixed = false;    // buffers are carved from a static workspace: never freed, never grown
     uint32_t n_cand = 0;   // state of the last scan, used by flacgpu_scan_frames
     // encode
     flacgpu::DevBuf e_streams, e_plans, e_frames, e_crc_off, e_crc_len, e_crc, e_windows, e_md5_T, e_stats, e_hints;
@@ -63,6 +65,7 @@ inline int fail(flacgpu_handle *h, int code, const std::string &msg)
 inline int reserve(flacgpu_handle *h, DevBuf &b, size_t bytes)
 {
     if (b.bytes >= bytes) return FLACGPU_OK;
+    if (h->fixed) return fail(h, FLACGPU_ERR_CAPACITY, "the batch needs more workspace than the entry point that allocates nothing has");
     if (b.p) { HIP_TRY(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
     size_t want = bytes + bytes / 8 + 256;
     HIP_TRY(hipMalloc(&b.p, want));

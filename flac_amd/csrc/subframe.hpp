@@ -1042,4 +1042,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     }
 }
 
+// ORs the class flags of one run of streams into a mask (bit = class index) that the timing report carries.
+__global__ void k_or_class_flags(const uint32_t *__restrict__ flags, uint32_t *__restrict__ mask)
+{
+    if (threadIdx.x < 6 && flags[threadIdx.x]) atomicOr(mask, 1u << threadIdx.x);
+}
+
 }  // namespace flacgpu

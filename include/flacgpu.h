@@ -266,6 +266,9 @@ typedef struct flacgpu_timing {
     uint64_t candidates;
     uint64_t in_bytes;
     uint64_t out_bytes;
+    uint32_t decode_classes;  /* decode kernel classes the batch used: bit (taps == 32) + 2 * arithmetic
+                                 (0 = 24-bit multiplies, 1 = 32-bit, 2 = 64-bit sums)             */
+    uint32_t reserved;
 } flacgpu_timing;
 
 /* Stream ordering (every entry point with a hip_stream argument).  hip_stream is a
@@ -301,6 +304,28 @@ int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in
                                 void *d_out, uint64_t out_bytes,
                                 const flacgpu_stream *streams, uint32_t n_streams,
                                 flacgpu_stream_result *results, void *hip_stream);
+
+/* The same decode for callers that cannot allocate device memory.  It has no counterpart in
+ * the reference (which has no device at all): it exists for code under HIP graph capture,
+ * tight serving loops and harnesses that forbid hipMalloc.  No handle: the workspace is a
+ * static device array of about 3.5 MiB that every GPU the library runs on holds until the
+ * process ends, so the call allocates and frees nothing (its first call on a device looks
+ * the array's address up and builds 1.3 KB of CRC tables in it).  Limits, checked, with
+ * FLACGPU_ERR_CAPACITY beyond them: in_bytes <= FLACGPU_NOALLOC_MAX_IN_BYTES, n_streams <=
+ * FLACGPU_NOALLOC_MAX_STREAMS, and at most FLACGPU_NOALLOC_MAX_CANDIDATES frame header
+ * candidates in the batch (frames plus false sync codes that pass CRC-8).  `device`: HIP
+ * device ordinal.  hip_stream: a hipStream_t; NULL is the legacy default stream.  Results
+ * equal those of flacgpu_decode_batch_device.  Every call on a GPU uses that GPU's one
+ * workspace: calls that overlap on one GPU race and must be serialised by the caller. */
+#define FLACGPU_NOALLOC_MAX_IN_BYTES   (4u << 20)
+#define FLACGPU_NOALLOC_MAX_STREAMS    256u
+#define FLACGPU_NOALLOC_MAX_CANDIDATES 32768u
+int flacgpu_decode_batch_device_noalloc(int device, const void *d_in, uint64_t in_bytes,
+                                        void *d_out, uint64_t out_bytes,
+                                        const flacgpu_stream *streams, uint32_t n_streams,
+                                        flacgpu_stream_result *results, void *hip_stream);
+/* Text of the last error of the entry point above on `device`. */
+const char *flacgpu_noalloc_last_error(int device);
 
 /* Host-buffer convenience: bufs[i] points at frame 0 of stream i (lens[i]
  * bytes); PCM lands in out_pcm[i] (out_caps[i] bytes).  Copies in and out over

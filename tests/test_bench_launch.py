@@ -1,0 +1,64 @@
+"""bench.py --gpus N starts its own ranks: the command it builds, its refusal on a node with fewer GPUs (CPU),
+and a two-rank run through the whole bench on one GPU in rehearsal mode (GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from util import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_launch_command_is_what_the_driver_runs():
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], 29512)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29512"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
+
+
+def test_presets_name_the_baseline_configurations():
+    assert bench.PRESETS["cfg3"] == {}
+    c = bench.PRESETS["cfg4"]
+    assert (c["rate"], c["channels"], c["bps"], c["blocksize"], c["force_lpc_order"], c["force_partition_order"]) == \
+        (192000, 8, 24, 16384, 32, 8)
+    assert c["files"] * c["seconds"] * c["rate"] * c["channels"] * 3 >= 8e9      # at least 8 GB of PCM per GPU
+
+
+def test_more_gpus_than_the_node_has_is_refused():
+    import torch
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FLAC_BENCH_REHEARSE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "not measurable here" in p.stderr and not p.stdout.strip()
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "WORLD_SIZE is 3" in p.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_started_by_bench_itself():
+    """`bench.py --gpus 2` with no launcher around it: two ranks (both on GPU 0, gloo for the timing scalars: a
+    one-GPU box cannot run two RCCL ranks), one JSON line, n_gpus 2, one timing per rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FLAC_BENCH_REHEARSE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--files", "24", "--unique", "4",
+                        "--seconds", "2", "--steps", "2", "--warmup", "1", "--cpu-files", "2", "--cpu-seconds", "0.2",
+                        "--encode-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["rank_ms_per_step"]) == 2 and out["scaling"] == "weak"
+    assert out["config"]["files_per_gpu"] == 24 and out["value"] > 0
+    assert 0 < out["roofline"]["pipeline_frac"] <= out["roofline"]["frac"] < 1
+    assert out["cpu_baseline"]["cores"] >= 1 and out["host"]["cpu_count"] >= 1 and out["device"]["compute_units"] > 0
