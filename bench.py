@@ -185,7 +185,8 @@ def dominant_decode_kernel(classes, channels, bytes_ps):
     (taps == 32) + 2 * arithmetic); with several classes the widest is named (it is the slowest per sample)."""
     if not classes:
         return "k_decode"
-    b = max(i for i in range(6) if classes >> i & 1)
+    width = {3: 0, 0: 1, 1: 2, 2: 3}        # arithmetic classes from narrowest (16-bit pairs) to widest (64-bit sums)
+    b = max((i for i in range(8) if classes >> i & 1), key=lambda i: (width[i >> 1], i & 1))
     return f"k_decode<{32 if b & 1 else 12}, {b >> 1}, {'true' if channels == 2 and bytes_ps == 2 else 'false'}>"
 
 

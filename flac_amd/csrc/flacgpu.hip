@@ -358,16 +358,20 @@ static int decode_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
         p.r_begin = r.r_begin; p.r_end = r.r_end; p.C = r.C; p.B = r.B;
         p.class_flags = (uint32_t *)h->counter.p + 4;
         p.check_flag = 0;
-        HIP_TRY(hipMemsetAsync(p.class_flags, 0, 6 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(p.class_flags, 0, 8 * sizeof(uint32_t), st));
         // every predictor-length class is launched over the same grid; a wave runs in exactly one
 #define FLACGPU_LAUNCH(MO, W, S) \
         k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C), st>>>(p); p.check_flag = 1
+        // the first launch classifies every wave, so it is the class most waves of such streams fall in
         if (r.C == 2 && r.B == 2) {
-            FLACGPU_LAUNCH(12, 0, true); FLACGPU_LAUNCH(32, 0, true); FLACGPU_LAUNCH(12, 1, true);
-            FLACGPU_LAUNCH(32, 1, true); FLACGPU_LAUNCH(12, 2, true); FLACGPU_LAUNCH(32, 2, true);
+            FLACGPU_LAUNCH(12, 3, true); FLACGPU_LAUNCH(32, 3, true); FLACGPU_LAUNCH(12, 0, true); FLACGPU_LAUNCH(32, 0, true);
+            FLACGPU_LAUNCH(12, 1, true); FLACGPU_LAUNCH(32, 1, true); FLACGPU_LAUNCH(12, 2, true); FLACGPU_LAUNCH(32, 2, true);
+        } else if (r.B <= 2) {
+            FLACGPU_LAUNCH(12, 3, false); FLACGPU_LAUNCH(32, 3, false); FLACGPU_LAUNCH(12, 0, false); FLACGPU_LAUNCH(32, 0, false);
+            FLACGPU_LAUNCH(12, 1, false); FLACGPU_LAUNCH(32, 1, false); FLACGPU_LAUNCH(12, 2, false); FLACGPU_LAUNCH(32, 2, false);
         } else {
-            FLACGPU_LAUNCH(12, 0, false); FLACGPU_LAUNCH(32, 0, false); FLACGPU_LAUNCH(12, 1, false);
-            FLACGPU_LAUNCH(32, 1, false); FLACGPU_LAUNCH(12, 2, false); FLACGPU_LAUNCH(32, 2, false);
+            FLACGPU_LAUNCH(12, 0, false); FLACGPU_LAUNCH(32, 0, false); FLACGPU_LAUNCH(12, 1, false); FLACGPU_LAUNCH(32, 1, false);
+            FLACGPU_LAUNCH(12, 2, false); FLACGPU_LAUNCH(32, 2, false); FLACGPU_LAUNCH(12, 3, false); FLACGPU_LAUNCH(32, 3, false);
         }
 #undef FLACGPU_LAUNCH
         if (h->flags & FLACGPU_FLAG_TIMING) k_or_class_flags<<<1, 64, 0, st>>>(p.class_flags, (uint32_t *)h->counter.p + 12);

@@ -42,7 +42,10 @@ constexpr uint32_t kRingLog2 = FLACGPU_RING_LOG2;
 constexpr uint32_t kRingWords = 1u << kRingLog2;   // ring capacity per lane, in 32-bit words
 constexpr uint32_t kRingSlots = kRingWords + 1;    // the last slot repeats slot 0, so that words w and w + 1 are always one two-word read
 constexpr uint32_t kUnitWords = 8;    // refill granule: 32 bytes
-constexpr uint32_t kRoundSteps = 8;   // decode steps (of at most 32 bits) between refill rounds
+#ifndef FLACGPU_ROUND_STEPS
+#define FLACGPU_ROUND_STEPS 8
+#endif
+constexpr uint32_t kRoundSteps = FLACGPU_ROUND_STEPS;   // decode steps (of at most 32 bits) between refill rounds
 constexpr uint32_t kRingBytesPerWave = kRingSlots * 64 * 4;
 constexpr uint32_t kNoFill = 0xFFFFFFFFu;
 // A lane fetches its next unit when it has this many unread words or fewer.  The unit lands one round later
@@ -62,6 +65,27 @@ __device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
     int32_t r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+
+// Two 16 x 16-bit products and an addend in one instruction: lo(a) * lo(b) + hi(a) * hi(b) + c, halves taken as
+// signed, sum wrapping in 32 bits.  Issues at the rate of the 24-bit multiply-add, so a predictor whose samples
+// and coefficients fit 16 bits costs half the multiplies.
+__device__ inline int32_t dot2_i16(uint32_t a, uint32_t b, int32_t c)
+{
+    int32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ inline int32_t dot2_i16(uint32_t a, uint32_t b)
+{
+    int32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (lo, hi) -> lo's low half in bits 0-15, hi's low half in bits 16-31
+__device__ inline uint32_t pack_lo_hi(int32_t lo, int32_t hi)
+{
+    return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
 }
 
 // MSB-first reader over one lane's bitstream.  Its whole state is a bit position P, counted from the
@@ -131,6 +155,17 @@ struct BitReader {
         lds_word *q = (lds_word *)(uintptr_t)mad_i24((int32_t)idx, -256, (int32_t)top);
         return __builtin_amdgcn_alignbit(q[0], q[64], Q);
     }
+    // The same in two halves, for loops that fetch the window of the next code before they finish the current one:
+    // the two ring words (no wait), and the funnel shift that needs them.
+    __device__ inline uint2 fetch_ring_neg(uint32_t Q) const
+    {
+        typedef __attribute__((address_space(3))) const uint32_t lds_word;
+        const uint32_t top = (uint32_t)(uintptr_t)(lds_word *)(ring + (kRingWords - 1) * 64);
+        const uint32_t idx = __builtin_amdgcn_ubfe(Q, 5, kRingLog2);
+        lds_word *q = (lds_word *)(uintptr_t)mad_i24((int32_t)idx, -256, (int32_t)top);
+        return uint2{q[0], q[64]};
+    }
+    static __device__ inline uint32_t window_neg(uint2 words, uint32_t Q) { return __builtin_amdgcn_alignbit(words.x, words.y, Q); }
     __device__ inline bool starved() const { return (P >> 5) + 1 >= fill; }
     __device__ inline uint32_t peek() const
     {
@@ -491,7 +526,7 @@ struct DecodeParams {
     uint32_t r_begin, r_end;
     uint32_t C;            // channels of every frame in [r_begin, r_end)
     uint32_t B;            // bytes per sample in the output
-    uint32_t *class_flags; // [6]: set when some wave of the run belongs to that (taps, arithmetic) class
+    uint32_t *class_flags; // [8]: set when some wave of the run belongs to that (taps, arithmetic) class
     uint32_t check_flag;   // leave at once when this instantiation's flag is not set
 };
 
@@ -521,7 +556,12 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 // One lane per (frame, channel); a wave holds floor(64 / C) frames.
 // NT: predictor taps evaluated per sample (12 or 32).
 // ARITH: 0 = 24-bit multiplies (every subframe of the wave is at most 24 bits wide),
-//        1 = 32-bit multiplies, 2 = 64-bit sums.
+//        1 = 32-bit multiplies, 2 = 64-bit sums,
+//        3 = every subframe at most 17 bits wide and no 64-bit sums: the unrolled body multiplies pairs of
+//            taps with v_dot2_i32_i16 on samples packed two to a register.  That is exact while the samples
+//            fit 16 bits, which a 17-bit side channel almost always does; a lane that meets one that does
+//            not is rolled back like a lane with an over-long Rice code, and the generic body (24-bit
+//            multiplies) decodes until its history fits again.
 // STEREO16: C == 2 and B == 2, the write-out specialised for it.
 // Lanes stage their samples as coded; stereo decorrelation and packing to the output's sample size happen
 // in the write-out, once per output word.
@@ -537,9 +577,16 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int U = class_unroll(NT);
-    constexpr uint32_t kT = kTile;
+    // 16-bit stereo in the 16-bit pair class stages its samples as 16-bit halves: twice as many samples fit the
+    // tile, and a write-out then covers whole 128-byte lines of every frame (64-byte halves of lines, written
+    // seconds of wave time apart, cost the memory system a quarter of the kernel's time).  The unrolled body of
+    // that class only keeps samples that fit 16 bits; the few that do not (generic body, 17-bit side channels)
+    // are marked in `widemask`, one bit per tile column, and send the write-out down its slow path.
+    constexpr bool TILE16 = STEREO16 && ARITH == 3;
+    constexpr uint32_t kT = TILE16 ? 2 * kTile : kTile;
     // The instantiation launched first runs every wave and flags the classes its waves turn out to belong
     // to; the launches that follow are over in microseconds when no wave is theirs.
+    constexpr bool DOT = ARITH == 3;
     if (p.check_flag && p.class_flags[(NT == 12 ? 0 : 1) + 2 * ARITH] == 0) return;
     const uint32_t C = STEREO16 ? 2u : p.C, B = STEREO16 ? 2u : p.B;
     const uint32_t CB = C * B;
@@ -549,6 +596,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     uint32_t *wave_ring = reinterpret_cast<uint32_t *>(smem + wave_in_block * wave_bytes);
     uint8_t *tile = smem + wave_in_block * wave_bytes + kRingBytesPerWave;
     uint32_t *tile_raw = reinterpret_cast<uint32_t *>(tile);
+    uint16_t *tile_half = reinterpret_cast<uint16_t *>(tile);   // TILE16: [column][lane], kRawStride halfwords per column
 
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const uint32_t fl = lane / C, ch = lane - fl * C;
@@ -588,13 +636,15 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     const uint32_t maxord = wave_max_u32(active && status == kFrameOK ? h.order : 0);
     const bool any_wide = __any(need_wide);
     const bool any_big = __any(active && status == kFrameOK && h.sbps > 24);
-    // a wave is decoded by exactly one instantiation: 12 or 32 taps x {24-bit, 32-bit, 64-bit} arithmetic
+    const bool any_over17 = __any(active && status == kFrameOK && h.sbps > 17);
+    // a wave is decoded by exactly one instantiation: 12 or 32 taps x {16-bit pairs, 24-bit, 32-bit, 64-bit} arithmetic
     const int cls = maxord <= 12 ? 12 : 32;
-    const int arith = any_wide ? 2 : any_big ? 1 : 0;
+    const int arith = any_wide ? 2 : any_big ? 1 : any_over17 ? 0 : 3;
     if (cls != NT || arith != ARITH) {
         if (lane == 0) p.class_flags[(cls == 12 ? 0 : 1) + 2 * arith] = 1;
         return;
     }
+    if (!p.check_flag && lane == 0) p.class_flags[(NT == 12 ? 0 : 1) + 2 * ARITH] = 1;   // for the timing report only
 
     const uint32_t bs_max = wave_max_u32(active ? bs : 0);
     // a frame's destination, block size (bits 0-19; 0 when the frame is not decoded) and channel assignment
@@ -609,9 +659,20 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // 16-bit stereo write-out: this lane packs sample columns 4*(lane & 3) .. +3 of frames 16*it + (lane >> 2),
     // it = 0, 1.  Their channel assignments (4 bits each), where they go (offset of the lane's first
     // column from p.out) and how long they are:
+    // With the 16-bit tile a row is 32 samples = 128 bytes: this lane packs sample columns 4*(lane & 7) .. +3 of
+    // frames 8*it + (lane >> 3), it = 0 .. 3.
+    constexpr int NIT = TILE16 ? 4 : 2;
     uint32_t modes = 0;
-    uint64_t fdst[2] = {0, 0};
-    uint32_t fbs[2] = {0, 0};
+    uint64_t fdst[NIT] = {};
+    uint32_t fbs[NIT] = {};
+    // The decorrelation of a pair (a, b), whatever the frame's channel assignment, as
+    //   left = a + lmul * ((b + half) >> half),  right = (a & rmask) + rmul * (b >> half)
+    // with per-frame constants: half = 1 for mid/side; lmul = 1 when b is a side channel that the left sample
+    // needs (side/right, mid/side); rmask = all ones and rmul = -1 when the right sample is a minus b's part
+    // (left/side, mid/side), else 0 and 1.
+    int32_t dc_half[NIT] = {}, dc_lmul[NIT] = {}, dc_rmul[NIT] = {};
+    uint32_t dc_rmask[NIT] = {};
+    bool row16[NIT] = {};   // the frame's rows of four words start on 16-byte boundaries
     // Other layouts: a frame's 16 samples x C channels are 16C sample slots in output order; a work item is
     // four consecutive slots of one frame (= B output dwords), 4C items per frame, item = 64 * it + lane,
     // it = 0 .. 3.  Divisions by C and 4C are multiplications by rounded-up 16-bit reciprocals (exact while
@@ -627,12 +688,18 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     uint32_t q_meta[4] = {};
     if (STEREO16) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const uint32_t f = it * 16 + (lane >> 2);
+        for (int it = 0; it < NIT; ++it) {
+            const uint32_t f = TILE16 ? it * 8 + (lane >> 3) : it * 16 + (lane >> 2);
             const uint32_t meta = frame_meta(f);
             modes |= ((meta >> 20) & 15u) << (4 * it);
-            fdst[it] = frame_dst(f) + (lane & 3) * 16;
+            fdst[it] = frame_dst(f) + (TILE16 ? (lane & 7) : (lane & 3)) * 16;
             fbs[it] = meta & 0xFFFFFu;
+            const uint32_t m = (meta >> 20) & 15u;
+            dc_half[it] = m == 10 ? 1 : 0;
+            dc_lmul[it] = (m == 9 || m == 10) ? 1 : 0;
+            dc_rmul[it] = (m == 8 || m == 10) ? -1 : 1;
+            dc_rmask[it] = (m == 8 || m == 10) ? 0xFFFFFFFFu : 0u;
+            row16[it] = dwords && ((reinterpret_cast<uint64_t>(p.out) + fdst[it]) & 15) == 0;
         }
     } else {
         const uint32_t tile_lds = (uint32_t)(uintptr_t)(lds_word *)tile_raw;
@@ -658,6 +725,18 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // ---- per-lane decoder state --------------------------------------------------------
     int32_t coef[NT];
     int32_t ring[U];    // ring[i] = most recent sample n with n % U == i
+    // 16-bit pair class: pk[i] = (sample n, sample n - 1) for the most recent n with n % U == i, as 16-bit halves;
+    // cp[i] = (coef[2i], coef[2i + 1]).  The packs are kept from one unrolled group to the next and rebuilt from
+    // `ring` after a generic group (packs_ok is the same in every lane).  hist16: this lane's last NT samples fit 16 bits.
+    constexpr int NP = NT / 2;
+    uint32_t pk[DOT ? U : 1], cp[DOT ? NP : 1];
+    bool packs_ok = false, hist16 = true;
+    if (DOT) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) cp[j] = 0;
+#pragma unroll
+        for (int j = 0; j < U; ++j) pk[j] = 0;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) coef[j] = 0;
 #pragma unroll
@@ -689,6 +768,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             if (order == 3) { coef[0] = 3; coef[1] = -3; coef[2] = 1; }
             if (order == 4) { coef[0] = 4; coef[1] = -6; coef[2] = 4; coef[3] = -1; }
         }
+        if (DOT) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) cp[j] = pack_lo_hi(coef[2 * j], coef[2 * j + 1]);   // coefficients have at most 15 bits
+        }
         const uint32_t method = br.read(2);
         const uint32_t po = br.read(4);
         if (method > 1) status = kFrameBadSubframe;
@@ -714,13 +797,29 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // Staging of one sample into the LDS tile; `col` = sample index inside the tile.  Samples that do not
     // fit the subframe's width mark the frame invalid: v + 2^(sbits-1) has no bit above sbits-1 exactly
     // when v is in range, and the OR of those sums is tested once at the end.
+    // The unrolled groups collect their sums in `govf`, which joins `ovf` only when the lane keeps the group's
+    // results.  In the 16-bit pair class a 17-bit lane tests its samples against 16 bits there instead (half_fast):
+    // not an error when it fails, but the group's products were wrong and the lane is redone.
     const uint32_t sbits = h.sbps ? h.sbps : 32u;
     const uint32_t half = 1u << (sbits - 1);
-    uint32_t ovf = 0;
+    const bool pair17 = DOT && h.sbps + h.wasted == 17;
+    const uint32_t fast_bits = pair17 ? 16u - h.wasted : sbits;   // what a sample of an unrolled group has to fit
+    const uint32_t half_fast = pair17 ? ((1u << fast_bits) >> 1) : half;
+    uint32_t ovf = 0, govf = 0;
+    // TILE16: columns of the current tile whose staged value (sample << wasted bits) does not fit 16 bits.  A
+    // constant subframe with such a value marks every column for good.
+    const uint32_t widemask_rest = (TILE16 && active && h.kind == 0 && ((((uint32_t)constval << h.wasted) + 0x8000u) >> 16)) ? 0xFFFFFFFFu : 0u;
+    uint32_t widemask = widemask_rest;
     auto emit = [&](int32_t v, bool live, uint32_t col, auto always) {
         constexpr bool ALWAYS = decltype(always)::value;   // fast groups store from every lane: a dead lane's column is never written out
-        ovf |= (uint32_t)v + half;
-        if (ALWAYS || live) tile_raw[col * kRawStride + lane] = (uint32_t)v << h.wasted;
+        if (ALWAYS) govf |= (uint32_t)v + half_fast; else ovf |= (uint32_t)v + half;
+        const uint32_t x = (uint32_t)v << h.wasted;
+        if (TILE16) {
+            if (!ALWAYS && live && ((x + 0x8000u) >> 16)) widemask |= 1u << col;
+            if (ALWAYS || live) tile_half[col * kRawStride + lane] = (uint16_t)x;
+        } else {
+            if (ALWAYS || live) tile_raw[col * kRawStride + lane] = x;
+        }
     };
     // Sum of coef[j] * x[j] over the NT taps in the wave's arithmetic class, shifted.  The taps are
     // summed in three independent chains and the most recent sample (tap 0) is added last: a dependent
@@ -767,42 +866,101 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     };
     // Write-out of the staged samples [t0, t0 + kT) of every frame of this wave.
     auto flush = [&](uint32_t t0) {
+#ifdef FLACGPU_ABL_NOFLUSH
+        if (t0 != 0xFFFFFFF0u) return;
+#endif
         __builtin_amdgcn_wave_barrier();
         if (STEREO16) {
-            // four output words (left | right << 16) per lane and step: 4 lanes write 64 contiguous bytes of one frame
-            const uint32_t c4 = (lane & 3) * 4;
-            uint2 ab[2][4];
+            // four output words (left | right << 16) per lane and row: the lanes of a row write 64 (TILE16: 128)
+            // contiguous bytes of one frame
+            const uint32_t c4 = (TILE16 ? (lane & 7) : (lane & 3)) * 4;
+            uint2 ab[NIT][4];
+            if (TILE16) {
+                // one word of the tile is a sample pair already: channel 0 in the low half, channel 1 in the high half
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
+                for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    ab[it][i] = *reinterpret_cast<const uint2 *>(tile_raw + (c4 + i) * kRawStride + 2 * (it * 16 + (lane >> 2)));
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t w = tile_raw[(c4 + i) * (kRawStride / 2) + it * 8 + (lane >> 3)];
+                        ab[it][i] = uint2{(uint32_t)__builtin_amdgcn_sbfe((int32_t)w, 0, 16), (uint32_t)((int32_t)w >> 16)};
+                    }
+            } else {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const uint32_t m = (modes >> (4 * it)) & 15u;
-                uint32_t word[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t a = ab[it][i].x, b = ab[it][i].y;
-                    uint32_t L, R;
-                    decorrelate(m, a, b, L, R);
-                    word[i] = (L & 0xFFFFu) | (R << 16);
-                }
-                const uint32_t n = t0 + c4;
-                uint8_t *at = p.out + fdst[it] + (uint64_t)t0 * 4;
-                if (dwords && n + 4 <= fbs[it] && (reinterpret_cast<uint64_t>(at) & 15) == 0) {
-                    *reinterpret_cast<uint4 *>(at) = uint4{word[0], word[1], word[2], word[3]};
-                } else {
+                for (int it = 0; it < NIT; ++it)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (n + i < fbs[it]) {
-                            uint8_t *q = at + 4 * i;
-                            const uint32_t x = word[i];
-                            if (dwords) *reinterpret_cast<uint32_t *>(q) = x;
-                            else { q[0] = (uint8_t)x; q[1] = (uint8_t)(x >> 8); q[2] = (uint8_t)(x >> 16); q[3] = (uint8_t)(x >> 24); }
-                        }
+                        ab[it][i] = *reinterpret_cast<const uint2 *>(tile_raw + (c4 + i) * kRawStride + 2 * (it * 16 + (lane >> 2)));
+            }
+            // every lane's rows inside their blocks and aligned (all tiles but a block's ragged last one, in
+            // waves whose frames are all being decoded), no staged value wider than its half word: no
+            // branches, seven instructions per output word
+            bool whole = true;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) whole = whole && row16[it] && t0 + c4 + 4 <= fbs[it];
+            if (TILE16) whole = whole && widemask == 0;
+            if (__all(whole)) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    uint32_t word[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int32_t a = (int32_t)ab[it][i].x, b = (int32_t)ab[it][i].y;
+                        const int32_t hb = b >> dc_half[it], hc = (b + dc_half[it]) >> dc_half[it];
+                        const int32_t L = mad_i24(hc, dc_lmul[it], a);
+                        const int32_t R = mad_i24(hb, dc_rmul[it], (int32_t)((uint32_t)a & dc_rmask[it]));
+                        word[i] = pack_lo_hi(L, R);
+                    }
+#ifdef FLACGPU_ABL_NOSTORE
+                    if (word[0] == 0x12345678u && word[1] == 0x9abcdef0u && word[2] == word[3])
+#endif
+                    *reinterpret_cast<uint4 *>(p.out + fdst[it] + (uint64_t)t0 * 4) = uint4{word[0], word[1], word[2], word[3]};
+                }
+            } else {
+#pragma unroll 1
+                for (int it = 0; it < NIT; ++it) {
+                    const uint32_t m = (modes >> (4 * it)) & 15u;
+                    uint32_t wm0 = 0, wm1 = 0;
+                    if (TILE16) {   // the frame's two lanes know which of their staged values lost their top bit
+                        const uint32_t f = (uint32_t)it * 8 + (lane >> 3);
+                        wm0 = (uint32_t)__shfl((int)widemask, (int)(2 * f));
+                        wm1 = (uint32_t)__shfl((int)widemask, (int)(2 * f + 1));
+                    }
+                    uint32_t word[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t a = 0, b = 0;
+#pragma unroll
+                        for (int k = 0; k < NIT; ++k)   // ab[] stays in registers: no dynamic index
+                            if (k == it) { a = ab[k][i].x; b = ab[k][i].y; }
+                        // a value that does not fit 16 bits has 17: its top bit is the inverse of bit 15
+                        if ((wm0 >> (c4 + i)) & 1) a ^= 0xFFFF0000u;
+                        if ((wm1 >> (c4 + i)) & 1) b ^= 0xFFFF0000u;
+                        uint32_t L, R;
+                        decorrelate(m, a, b, L, R);
+                        word[i] = (L & 0xFFFFu) | (R << 16);
+                    }
+                    uint64_t dst_it = 0;
+                    uint32_t bs_it = 0;
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k)
+                        if (k == it) { dst_it = fdst[k]; bs_it = fbs[k]; }
+                    const uint32_t n = t0 + c4;
+                    uint8_t *at = p.out + dst_it + (uint64_t)t0 * 4;
+                    if (dwords && n + 4 <= bs_it && (reinterpret_cast<uint64_t>(at) & 15) == 0) {
+                        *reinterpret_cast<uint4 *>(at) = uint4{word[0], word[1], word[2], word[3]};
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (n + i < bs_it) {
+                                uint8_t *q = at + 4 * i;
+                                const uint32_t x = word[i];
+                                if (dwords) *reinterpret_cast<uint32_t *>(q) = x;
+                                else { q[0] = (uint8_t)x; q[1] = (uint8_t)(x >> 8); q[2] = (uint8_t)(x >> 16); q[3] = (uint8_t)(x >> 24); }
+                            }
+                    }
                 }
             }
+            widemask = widemask_rest;
         } else {
             // the 4 * B output bytes of four slots as dwords d0 .. d(B-1); B == 4: the slots themselves
             auto pack = [&](const uint32_t (&v)[4], uint32_t &d0, uint32_t &d1, uint32_t &d2) {
@@ -884,12 +1042,16 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // samples: its predictor parameters still have to be consumed.
     RingFetch rf;
     rf.clear();
+    // A refill round consumes the loads of the round before it, and a wave's loads and stores complete in
+    // issue order: a round that follows a write-out waits for the write-out's stores as well.  So the round
+    // between two groups runs before the write-out, not after it, and the stores have half a group to
+    // complete before the next round (in the middle of the next group) has to wait for them.
+    ring_round(br, rf, active && status == kFrameOK);
     ring_round(br, rf, active && status == kFrameOK);
     ring_round(br, rf, active && status == kFrameOK);
     const bool trailing = __any(active && status == kFrameOK && kind == 2 && order >= bs);
     const uint32_t n_end = ((bs_max + U - 1) / U) * U + (trailing ? U : 0);
     for (uint32_t n0 = 0; n0 < n_end; n0 += U) {
-        ring_round(br, rf, active && status == kFrameOK);
         const bool on = active && status == kFrameOK && n0 < bs;
         if (on && kind == 2 && started && part_rem == 0) next_partition();
         if (on && br.pos() > limit) status = kFrameTruncated;
@@ -897,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
         const bool unstarted = active && status == kFrameOK && kind == 2 && !started;
         const bool simple = unstarted ? false
                                       : (!on || kind == 0 ||
-                                         (rice_on && !escaped && part_rem >= (uint32_t)U && n0 + U <= bs));
+                                         (rice_on && !escaped && part_rem >= (uint32_t)U && n0 + U <= bs && (!DOT || hist16)));
         bool redo = true;            // lanes the generic body below has to process
 #ifdef FLACGPU_DEBUG_NO_FAST
         bool run_generic = true;
@@ -912,7 +1074,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             // and the generic body redoes the group for it.  Lanes that have no residual to
             // read (constant subframes, blocks that have ended) let their reader run along and
             // get it back afterwards.
-            const uint32_t s_P = br.P, s_ovf = ovf;
+            const uint32_t s_P = br.P;
+            govf = 0;
+            if (DOT && !packs_ok) {
+#pragma unroll
+                for (int m = U - 1; m >= U - NT + 1; m -= 1) pk[m] = pack_lo_hi(ring[m], ring[m - 1]);
+            }
             int32_t s_hist[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) s_hist[j] = ring[U - 1 - j];
@@ -920,27 +1087,59 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             bool starved = false;
             uint32_t Q = 0u - br.P;              // the read position, negated (see peek_ring_neg)
             const uint32_t neg_k1 = 0u - (k + 1);
+            // The window of a code is fetched as soon as the code before it has given its length, ahead of that
+            // code's own arithmetic and of its store to the tile: LDS operations stay in program order, and a
+            // fetch placed after the store would leave the LDS latency exposed once per sample.  The window of
+            // the code after a refill round is fetched before the round writes to the ring: the words it needs
+            // were there already unless the lane is starved, which the round's test finds out.
+            // The scheduler would sink the fetch below the store again (it sees a short latency and no conflict);
+            // the scheduling barrier after the fetch keeps the rest of the sample's instructions behind it.
+            uint2 raw = br.fetch_ring_neg(Q);
+            uint32_t Qf = Q;
 #pragma unroll
             for (int P = 0; P < U; ++P) {
-                if (P && P % kRoundSteps == 0) {
+                // Rice code: unary part = leading zeros of the window, then k low bits.  The code's length
+                // nb = q + 1 + k is kept negated: -nb mod 32 is where the low bits start, and it advances Q.
+                const uint32_t w = BitReader::window_neg(raw, Qf);
+                const uint32_t q = lead_zeros_raw(w);
+                longest_q |= q;
+                const uint32_t neg_nb = neg_k1 - q;
+                Q += neg_nb;
+                if (P + 1 < U) {
+                    raw = br.fetch_ring_neg(Q);
+                    Qf = Q;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const uint32_t low = bfe_mod32(w, neg_nb, k);
+                const int32_t res = unzigzag((q << k) | low);
+                int32_t pred;
+                if (DOT) {
+                    // pair i = taps 2i and 2i + 1 = samples n - 1 - 2i and n - 2 - 2i = pk[(n - 1 - 2i) % U]; two chains,
+                    // and the pair with the newest sample, the only one that waits for the previous result, last
+                    int32_t sa = 0, sb = 0;
+#pragma unroll
+                    for (int i = 1; i < NP; ++i) {
+                        const uint32_t x = pk[(P + 2 * U - 1 - 2 * i) % U];
+                        if (i & 1) sa = i == 1 ? dot2_i16(x, cp[i]) : dot2_i16(x, cp[i], sa);
+                        else sb = i == 2 ? dot2_i16(x, cp[i]) : dot2_i16(x, cp[i], sb);
+                    }
+                    pred = dot2_i16(pk[(P + U - 1) % U], cp[0], sa + sb) >> shift;
+                } else {
+                    pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
+                }
+#ifdef FLACGPU_ABL_NOMAC
+                pred = 0;
+#endif
+                const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
+                ring[P] = v;
+                if (DOT) pk[P] = pack_lo_hi(v, ring[(P + U - 1) % U]);
+                emit(v, on, ((n0 + (uint32_t)P) & (kT - 1)), std::true_type{});
+                if ((P + 1) % kRoundSteps == 0 && P + 1 < U) {   // the refill round between samples P and P + 1 (before a write-out, see above)
                     br.P = 0u - Q;
                     starved = starved || br.starved();
                     ring_round(br, rf, rice_on);
                 }
-                // Rice code: unary part = leading zeros of the window, then k low bits.  The code's length
-                // nb = q + 1 + k is kept negated: -nb mod 32 is where the low bits start, and it advances Q.
-                const uint32_t w = br.peek_ring_neg(Q);
-                const uint32_t q = lead_zeros_raw(w);
-                longest_q |= q;
-                const uint32_t neg_nb = neg_k1 - q;
-                const uint32_t low = bfe_mod32(w, neg_nb, k);
-                const int32_t res = unzigzag((q << k) | low);
-                Q += neg_nb;
-                const int32_t pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
-                const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
-                ring[P] = v;
-                emit(v, on, (uint32_t)P & (kT - 1), std::true_type{});
-                if (U > (int)kTile && P == (int)kTile - 1) flush(n0);
+                if (U > (int)kT && P == (int)kT - 1) flush(n0);
             }
             br.P = 0u - Q;
             starved = starved || br.starved();
@@ -951,11 +1150,14 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             // as 2^32 - 1 zeros), so the test never misses one; it is wrong the safe way now and then.
             redo = rice_on && (starved || longest_q > 31 - k);
 #endif
+            // a sample that does not fit 16 bits (less its wasted bits: the tile holds 16) was multiplied and staged as if it did
+            if (pair17) redo = redo || (rice_on && (govf >> fast_bits));
+            else if (!redo) ovf |= govf;
             if (rice_on && !redo) part_rem -= U;
             run_generic = __any(redo);
+            packs_ok = !run_generic;
             if (redo || !rice_on) br.P = s_P;
             if (redo) {
-                ovf = s_ovf;
                 // the refill round inside the group acted on the speculative read position: forget the
                 // ring (words come from global memory until the next rounds have refilled it)
                 br.fill = (s_P >> 5) & ~(kUnitWords - 1);
@@ -974,15 +1176,15 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             auto restage = [&](int first) {
                 if (!redo) {
 #pragma unroll
-                    for (int P = 0; P < (int)kTile; ++P)
+                    for (int P = 0; P < (int)kT; ++P)
                         tile_raw[(uint32_t)P * kRawStride + lane] = (uint32_t)ring[(first + P) % U] << h.wasted;
                 }
             };
-            if (U > (int)kTile) restage(0);
+            if (U > (int)kT) restage(0);
             for (uint32_t n = n0; n < n0 + U; ++n) {
                 if (n != n0 && ((n - n0) % kRoundSteps) == 0)
                     ring_round(br, rf, active && status == kFrameOK);
-                if (U > (int)kTile && n - n0 == kTile) { flush(n0); restage((int)kTile); }
+                if (U > (int)kT && n - n0 == kT) { flush(n0); restage((int)kT); }
                 const bool ok = active && status == kFrameOK && redo;
                 const bool live = ok && n < bs;
                 if (ok && kind == 2 && !started && n >= order) {
@@ -1018,8 +1220,16 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) ring[U - 1 - j] = hist[j];
+            if (DOT) {
+                uint32_t t = 0;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) t |= (uint32_t)hist[j] + 0x8000u;
+                hist16 = (t >> 16) == 0;
+                packs_ok = false;
+            }
         }
         const uint32_t done = n0 + U;
+        ring_round(br, rf, active && status == kFrameOK);
         if ((done & (kT - 1)) == 0 || done >= n_end) {
             const uint32_t t0 = (done - 1) & ~(kT - 1);   // tile that holds the group's last sample
             if (t0 < bs_max) flush(t0);
@@ -1045,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 // ORs the class flags of one run of streams into a mask (bit = class index) that the timing report carries.
 __global__ void k_or_class_flags(const uint32_t *__restrict__ flags, uint32_t *__restrict__ mask)
 {
-    if (threadIdx.x < 6 && flags[threadIdx.x]) atomicOr(mask, 1u << threadIdx.x);
+    if (threadIdx.x < 8 && flags[threadIdx.x]) atomicOr(mask, 1u << threadIdx.x);
 }
 
 }  // namespace flacgpu

@@ -267,7 +267,7 @@ typedef struct flacgpu_timing {
     uint64_t in_bytes;
     uint64_t out_bytes;
     uint32_t decode_classes;  /* decode kernel classes the batch used: bit (taps == 32) + 2 * arithmetic
-                                 (0 = 24-bit multiplies, 1 = 32-bit, 2 = 64-bit sums)             */
+                                 (0 = 24-bit multiplies, 1 = 32-bit, 2 = 64-bit sums, 3 = 16-bit pairs) */
     uint32_t reserved;
 } flacgpu_timing;
 
