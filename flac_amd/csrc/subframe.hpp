@@ -540,6 +540,9 @@ struct __attribute__((packed, aligned(4))) Dwords3 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(4))) Dwords4 { uint32_t a, b, c, d; };
 
 constexpr uint32_t kTile = 16;        // samples staged in LDS between write-outs
+constexpr uint32_t kPairStride = 68;  // 16-bit stereo, 16-bit pair class: words per pair of sample columns (one word per lane holds two
+                                      // consecutive samples): 64 lanes + 4, so that the write-out's 8-byte reads (one frame's two
+                                      // channels; 32 lanes: 4 frames x 8 column pairs) cover all 64 banks once
 constexpr uint32_t kRawStride = 66;   // words per sample column of the tile: 64 lanes + 2, so that the write-out's
                                       // 8-byte reads of 16-bit stereo (16 lanes: 4 frames x 4 columns) cover all banks once
 
@@ -550,7 +553,7 @@ constexpr uint32_t kRawStride = 66;   // words per sample column of the tile: 64
 __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 {
     (void)C;
-    return kRingBytesPerWave + kTile * kRawStride * 4;
+    return kRingBytesPerWave + kTile * kPairStride * 4;   // the larger of the two tile layouts
 }
 
 // One lane per (frame, channel); a wave holds floor(64 / C) frames.
@@ -573,7 +576,7 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 // boundary inside the group, escape-coded or verbatim data, the tail of a block)
 // runs the generic rolled body with a shift-register history.
 template <int NT, int ARITH, bool STEREO16>
-__global__ __launch_bounds__(256) void k_decode(DecodeParams p)
+__global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p)   // LDS admits three blocks per CU; the 12-tap classes keep their registers within that
 {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int U = class_unroll(NT);
@@ -596,7 +599,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     uint32_t *wave_ring = reinterpret_cast<uint32_t *>(smem + wave_in_block * wave_bytes);
     uint8_t *tile = smem + wave_in_block * wave_bytes + kRingBytesPerWave;
     uint32_t *tile_raw = reinterpret_cast<uint32_t *>(tile);
-    uint16_t *tile_half = reinterpret_cast<uint16_t *>(tile);   // TILE16: [column][lane], kRawStride halfwords per column
+    // TILE16: [column pair][lane] words; a word = (sample 2j + 1 in the low half, sample 2j in the high half) of its
+    // lane, which is how the 16-bit pair class packs its history anyway
+    uint16_t *tile_half = reinterpret_cast<uint16_t *>(tile);
+    typedef short pair16 __attribute__((ext_vector_type(2)));
 
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const uint32_t fl = lane / C, ch = lane - fl * C;
@@ -672,6 +678,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     // (left/side, mid/side), else 0 and 1.
     int32_t dc_half[NIT] = {}, dc_lmul[NIT] = {}, dc_rmul[NIT] = {};
     uint32_t dc_rmask[NIT] = {};
+    uint32_t dc_half2[NIT] = {}, dc_lmul2[NIT] = {}, dc_rmul2[NIT] = {};   // the same in both 16-bit halves of a word
     bool row16[NIT] = {};   // the frame's rows of four words start on 16-byte boundaries
     // Other layouts: a frame's 16 samples x C channels are 16C sample slots in output order; a work item is
     // four consecutive slots of one frame (= B output dwords), 4C items per frame, item = 64 * it + lane,
@@ -699,6 +706,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             dc_lmul[it] = (m == 9 || m == 10) ? 1 : 0;
             dc_rmul[it] = (m == 8 || m == 10) ? -1 : 1;
             dc_rmask[it] = (m == 8 || m == 10) ? 0xFFFFFFFFu : 0u;
+            dc_half2[it] = (uint32_t)dc_half[it] * 0x10001u;
+            dc_lmul2[it] = (uint32_t)dc_lmul[it] * 0x10001u;
+            dc_rmul2[it] = ((uint32_t)dc_rmul[it] & 0xFFFFu) * 0x10001u;
             row16[it] = dwords && ((reinterpret_cast<uint64_t>(p.out) + fdst[it]) & 15) == 0;
         }
     } else {
@@ -815,8 +825,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
         if (ALWAYS) govf |= (uint32_t)v + half_fast; else ovf |= (uint32_t)v + half;
         const uint32_t x = (uint32_t)v << h.wasted;
         if (TILE16) {
-            if (!ALWAYS && live && ((x + 0x8000u) >> 16)) widemask |= 1u << col;
-            if (ALWAYS || live) tile_half[col * kRawStride + lane] = (uint16_t)x;
+            // generic groups store sample by sample; the unrolled groups store their packed pairs themselves
+            if (!ALWAYS && live) {
+                if ((x + 0x8000u) >> 16) widemask |= 1u << col;
+                tile_half[((col >> 1) * kPairStride + lane) * 2 + (~col & 1u)] = (uint16_t)x;
+            }
         } else {
             if (ALWAYS || live) tile_raw[col * kRawStride + lane] = x;
         }
@@ -866,7 +879,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
     };
     // Write-out of the staged samples [t0, t0 + kT) of every frame of this wave.
     auto flush = [&](uint32_t t0) {
-#ifdef FLACGPU_ABL_NOFLUSH
+#ifdef FLACGPU_ABL_NOFLUSH   // ablation build: what the write-out costs in all
         if (t0 != 0xFFFFFFF0u) return;
 #endif
         __builtin_amdgcn_wave_barrier();
@@ -874,23 +887,21 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
             // four output words (left | right << 16) per lane and row: the lanes of a row write 64 (TILE16: 128)
             // contiguous bytes of one frame
             const uint32_t c4 = (TILE16 ? (lane & 7) : (lane & 3)) * 4;
-            uint2 ab[NIT][4];
-            if (TILE16) {
-                // one word of the tile is a sample pair already: channel 0 in the low half, channel 1 in the high half
+            // one row's four sample pairs (a, b) = (channel 0, channel 1)
+            auto load_row = [&](int it, uint2 (&ab)[4]) {
+                if (TILE16) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t w = tile_raw[(c4 + i) * (kRawStride / 2) + it * 8 + (lane >> 3)];
-                        ab[it][i] = uint2{(uint32_t)__builtin_amdgcn_sbfe((int32_t)w, 0, 16), (uint32_t)((int32_t)w >> 16)};
+                    for (int j = 0; j < 2; ++j) {   // a column pair: both channels' packed words of the frame
+                        const uint2 w = *reinterpret_cast<const uint2 *>(tile_raw + (c4 / 2 + j) * kPairStride + 2 * (it * 8 + (lane >> 3)));
+                        ab[2 * j] = uint2{(uint32_t)((int32_t)w.x >> 16), (uint32_t)((int32_t)w.y >> 16)};
+                        ab[2 * j + 1] = uint2{(uint32_t)__builtin_amdgcn_sbfe((int32_t)w.x, 0, 16), (uint32_t)__builtin_amdgcn_sbfe((int32_t)w.y, 0, 16)};
                     }
-            } else {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it)
+                } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        ab[it][i] = *reinterpret_cast<const uint2 *>(tile_raw + (c4 + i) * kRawStride + 2 * (it * 16 + (lane >> 2)));
-            }
+                        ab[i] = *reinterpret_cast<const uint2 *>(tile_raw + (c4 + i) * kRawStride + 2 * (it * 16 + (lane >> 2)));
+                }
+            };
             // every lane's rows inside their blocks and aligned (all tiles but a block's ragged last one, in
             // waves whose frames are all being decoded), no staged value wider than its half word: no
             // branches, seven instructions per output word
@@ -902,15 +913,34 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     uint32_t word[4];
+                    if (TILE16) {
+                        // two samples at a time in 16-bit halves (everything staged fits them, and only the low 16
+                        // bits of a result are stored): four instructions per output word
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int32_t a = (int32_t)ab[it][i].x, b = (int32_t)ab[it][i].y;
-                        const int32_t hb = b >> dc_half[it], hc = (b + dc_half[it]) >> dc_half[it];
-                        const int32_t L = mad_i24(hc, dc_lmul[it], a);
-                        const int32_t R = mad_i24(hb, dc_rmul[it], (int32_t)((uint32_t)a & dc_rmask[it]));
-                        word[i] = pack_lo_hi(L, R);
+                        for (int j = 0; j < 2; ++j) {
+                            const uint2 w = *reinterpret_cast<const uint2 *>(tile_raw + (c4 / 2 + j) * kPairStride + 2 * (it * 8 + (lane >> 3)));
+                            const pair16 a = __builtin_bit_cast(pair16, w.x), b = __builtin_bit_cast(pair16, w.y);
+                            const pair16 hf = __builtin_bit_cast(pair16, dc_half2[it]);
+                            const pair16 hb = b >> hf, hc = hb + (b & hf);
+                            const pair16 L = hc * __builtin_bit_cast(pair16, dc_lmul2[it]) + a;
+                            const pair16 R = hb * __builtin_bit_cast(pair16, dc_rmul2[it]) + (a & __builtin_bit_cast(pair16, dc_rmask[it]));
+                            const uint32_t l = __builtin_bit_cast(uint32_t, L), r = __builtin_bit_cast(uint32_t, R);
+                            word[2 * j] = __builtin_amdgcn_perm(r, l, 0x07060302u);       // the earlier sample sits in the high halves
+                            word[2 * j + 1] = __builtin_amdgcn_perm(r, l, 0x05040100u);
+                        }
+                    } else {
+                        uint2 ab[4];
+                        load_row(it, ab);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int32_t a = (int32_t)ab[i].x, b = (int32_t)ab[i].y;
+                            const int32_t hb = b >> dc_half[it], hc = (b + dc_half[it]) >> dc_half[it];
+                            const int32_t L = mad_i24(hc, dc_lmul[it], a);
+                            const int32_t R = mad_i24(hb, dc_rmul[it], (int32_t)((uint32_t)a & dc_rmask[it]));
+                            word[i] = pack_lo_hi(L, R);
+                        }
                     }
-#ifdef FLACGPU_ABL_NOSTORE
+#ifdef FLACGPU_ABL_NOSTORE   // ablation build: everything but the stores themselves (the words never have these values)
                     if (word[0] == 0x12345678u && word[1] == 0x9abcdef0u && word[2] == word[3])
 #endif
                     *reinterpret_cast<uint4 *>(p.out + fdst[it] + (uint64_t)t0 * 4) = uint4{word[0], word[1], word[2], word[3]};
@@ -925,13 +955,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                         wm0 = (uint32_t)__shfl((int)widemask, (int)(2 * f));
                         wm1 = (uint32_t)__shfl((int)widemask, (int)(2 * f + 1));
                     }
+                    uint2 ab[4];
+                    load_row(it, ab);
                     uint32_t word[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        uint32_t a = 0, b = 0;
-#pragma unroll
-                        for (int k = 0; k < NIT; ++k)   // ab[] stays in registers: no dynamic index
-                            if (k == it) { a = ab[k][i].x; b = ab[k][i].y; }
+                        uint32_t a = ab[i].x, b = ab[i].y;
                         // a value that does not fit 16 bits has 17: its top bit is the inverse of bit 15
                         if ((wm0 >> (c4 + i)) & 1) a ^= 0xFFFF0000u;
                         if ((wm1 >> (c4 + i)) & 1) b ^= 0xFFFF0000u;
@@ -1127,13 +1156,14 @@ __global__ __launch_bounds__(256) void k_decode(DecodeParams p)
                 } else {
                     pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
                 }
-#ifdef FLACGPU_ABL_NOMAC
-                pred = 0;
-#endif
                 const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
                 ring[P] = v;
                 if (DOT) pk[P] = pack_lo_hi(v, ring[(P + U - 1) % U]);
                 emit(v, on, ((n0 + (uint32_t)P) & (kT - 1)), std::true_type{});
+                if (TILE16 && (P & 1)) {   // samples P - 1 and P, both known to fit 16 bits if the lane keeps this group
+                    const pair16 shifted = __builtin_bit_cast(pair16, pk[P]) << pair16{(short)h.wasted, (short)h.wasted};
+                    tile_raw[(((n0 & (kT - 1)) + (uint32_t)P) >> 1) * kPairStride + lane] = __builtin_bit_cast(uint32_t, shifted);
+                }
                 if ((P + 1) % kRoundSteps == 0 && P + 1 < U) {   // the refill round between samples P and P + 1 (before a write-out, see above)
                     br.P = 0u - Q;
                     starved = starved || br.starved();

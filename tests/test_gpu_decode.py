@@ -261,6 +261,54 @@ def test_long_rice_codes_among_32_tap_neighbours(decoder):
         assert r.frames_ok == ost.frames_ok == 4
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_side_channels_wider_than_16_bits(decoder, mode):
+    """16-bit stereo with a side channel that needs its 17th bit.  The decode class for such streams multiplies
+    sample pairs as 16-bit halves and stages 16-bit halves for the write-out, assuming what almost always holds:
+    that side samples fit 16 bits.  Here they do not, in every way there is: stretches of opposite full-scale
+    channels in otherwise quiet streams (lanes rolled back among lanes that keep their results), streams that are
+    wide throughout, wide constant side channels, wasted bits below a wide side channel, wide warm-up samples,
+    and wide samples at the ragged end of a stream.  Each stereo coding (left/side, side/right, mid/side)."""
+    rng = np.random.default_rng(1700 + mode)
+    files, srcs = [], []
+
+    def add(x, bs=1024, order=12, **kw):
+        f, _ = synth.encode(x.astype(np.int32), 16, 44100, synth.options(bs, order, stereo_mode=mode, **kw))
+        files.append(bytes(f))
+        srcs.append(synth.pack_pcm(x.astype(np.int32), 16))
+
+    n = 1024 * 6 + 517
+    t = np.arange(n)
+    tone = (9000 * np.sin(t / 7.0)).astype(np.int64)
+    for k in range(10):                                   # quiet and correlated, with stretches of opposite full scale
+        x = np.stack([tone + rng.integers(-40, 40, n), tone + rng.integers(-40, 40, n)], axis=1)
+        for at in rng.integers(0, n - 40, size=6):
+            w = int(rng.integers(1, 40))
+            x[at:at + w, 0] = 32767 - rng.integers(0, 3, w)
+            x[at:at + w, 1] = -32768 + rng.integers(0, 3, w)
+        x[n - 3:, 0], x[n - 3:, 1] = -32768, 32767            # ... and at the ragged end
+        add(x, order=int(rng.choice([2, 8, 12])))
+    x = np.stack([rng.integers(20000, 32768, n), -rng.integers(20000, 32768, n)], axis=1)
+    add(x)                                                # wide throughout (side around +-60000)
+    add(x, order=0)                                       # ... with fixed predictors
+    add(x, bs=4096, order=32)                             # ... and the 32-tap class
+    x = np.empty((n, 2), dtype=np.int64)
+    x[:, 0], x[:, 1] = 30000, -30000                      # constant subframes, side = 60000
+    x[n // 2:, 0] = 29999
+    add(x)
+    x = (np.stack([rng.integers(16000, 32768, n), -rng.integers(16000, 32768, n)], axis=1) >> 3) << 3
+    add(x)                                                # wasted bits below a wide side channel
+    x = np.stack([tone, tone + 5], axis=1)
+    x[:12, 0], x[:12, 1] = 32767, -32768                  # wide warm-up samples only
+    add(x)
+    pcms, res, infos = gpu_batch(decoder, files, out_fill=0x33)
+    for f, pcm, src, si, r in zip(files, pcms, srcs, infos, res):
+        want, ost = oracle_decode(si, split_file(f)[1])
+        assert bytes(want) == src and md5hex(src) == si.md5_signature
+        assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples)
+        assert np.array_equal(pcm, want)
+
+
 def test_full_scale_noise_outruns_the_refill_schedule(decoder):
     """White noise at full scale is incompressible: nearly bps bits per code, so the lanes consume their
     bit-reader rings as fast as the refill rounds can fill them and some run dry inside the unrolled loop
