@@ -245,6 +245,7 @@ def main(argv=None):
     ap.add_argument("--cpu-files", type=int, default=256, help="files of the workload timed on the host CPU (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU sample is decoded repeatedly for about this long")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
+    ap.add_argument("--host-files", type=int, default=128, help="files decoded through the host-buffer entry point for the PCIe-inclusive rate (0 = skip)")
     ap.add_argument("--encode-steps", type=int, default=2, help="timed steps of the encode leg (0 = skip it)")
     pre = ap.parse_known_args(argv)[0]
     ap.set_defaults(**PRESETS[pre.config])
@@ -449,6 +450,26 @@ def main(argv=None):
                "sample": f"{ncpu} of the {unique} unique files ({ncpu * pcm_bytes_per_file / 1e6:.0f} MB PCM) decoded {passes} times, "
                          f"oracle/flac_oracle.c, {threads} threads, {cpu_s:.2f} s"}
 
+    # ---- the host-buffer entry point on a sample: the rate a caller with pageable buffers sees, PCIe both ways ----
+    pcie = None
+    if rank == 0 and args.host_files > 0:
+        nh = min(args.host_files, nfiles)
+        h_audio = [audios[i % unique] for i in range(nh)]
+        h_infos = [infos[i % unique] for i in range(nh)]
+        dec.decode_batch(h_audio, h_infos)                       # staging buffers and device arenas grow once
+        t0 = time.perf_counter()
+        h_pcm, h_res = dec.decode_batch(h_audio, h_infos)
+        h_s = time.perf_counter() - t0
+        assert all(r.frames_ok == exp_frames for r in h_res) or not check
+        if check:
+            assert hashlib.md5(h_pcm[0].tobytes()).hexdigest() == infos[0].md5_signature, "host-buffer path: MD5 mismatch"
+        h_bytes = sum(a.size for a in h_audio) + nh * pcm_bytes_per_file
+        pcie = {"value": nh * nsamples * channels / h_s, "unit": "samples/s", "files": nh, "seconds": h_s,
+                "bus_GB_per_s": h_bytes / h_s / 1e9,
+                "what": "flacgpu_decode_batch: caller's pageable buffers in and out, staged through pinned memory in chunks "
+                        "(copy in, decode and copy out of consecutive chunks overlap)"}
+        del h_pcm
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         alg_bytes = comp_total + pcm_total            # per launch of the decode kernel (one rank)
@@ -498,6 +519,7 @@ def main(argv=None):
             "device": device,
             "host": host_description(),
             "cpu_baseline": cpu,
+            "pcie_inclusive": pcie,
             "md5_verified": md5_check,
             "encode": enc,
         }

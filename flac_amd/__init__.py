@@ -456,7 +456,7 @@ class Decoder:
         """Host buffers in, host PCM out (copies over PCIe).  audio_list: per stream the bytes from frame 0."""
         n = len(audio_list)
         arrs = [np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8)) for a in audio_list]
-        outs = [np.zeros(si.pcm_bytes, dtype=np.uint8) for si in infos]
+        outs = [np.empty(si.pcm_bytes, dtype=np.uint8) for si in infos]   # the library fills every byte (zeros where a frame failed)
         bufs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
         lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
         sis = (StreamInfo * n)()
@@ -502,7 +502,7 @@ class Decoder:
         n = len(pcm_list)
         arrs = [np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8)) for a in pcm_list]
         caps = [encode_bound(sh[0], sh[2], sh[3], opts.blocksize, opts.seektable_interval) for sh in shapes]
-        outs = [np.zeros(c, dtype=np.uint8) for c in caps]
+        outs = [np.empty(c, dtype=np.uint8) for c in caps]   # only out_length bytes of each are meaningful
         streams = self.make_pcm_streams((0, sh[0], 0, 0, sh[1], sh[2], sh[3], sh[4] if len(sh) > 4 else None)
                                         for sh in shapes)
         iptr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])

@@ -26,6 +26,7 @@
 using namespace flacgpu;
 
 #include "handle.hpp"
+#include "host_stage.hpp"
 
 namespace {
 
@@ -195,6 +196,17 @@ void collect_timing(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes)
 
 namespace flacgpu {
 
+HostPipe *host_pipe(flacgpu_handle *h)
+{
+    if (!h->pipe) h->pipe = new HostPipe();
+    return h->pipe;
+}
+
+void host_pipe_release(flacgpu_handle *h)
+{
+    if (h->pipe) { pipe_release(*h->pipe); delete h->pipe; h->pipe = nullptr; }
+}
+
 void launch_crc16_spans(flacgpu_handle *h, const uint8_t *base, const uint64_t *off, const uint32_t *len, uint16_t *crc,
                         uint32_t n, hipStream_t st)
 {
@@ -243,6 +255,7 @@ void flacgpu_destroy(flacgpu_handle *h)
                      &h->counter, &h->crc_tables, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
                      &h->seglen, &h->subpos, &h->next};
     for (DevBuf *b : all) release(*b);
+    host_pipe_release(h);
     encode_release(h);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -520,32 +533,32 @@ int flacgpu_decode_batch(flacgpu_handle *h, const uint8_t *const *bufs, const ui
 {
     if (!h || !bufs || !lens || !infos || !out_pcm || !out_caps || !n_streams) return fail(h, FLACGPU_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    std::vector<flacgpu_stream> streams(n_streams);
-    uint64_t in_total = 0, out_total = 0;
+    std::vector<HostItem> items(n_streams);
     for (uint32_t i = 0; i < n_streams; ++i) {
-        streams[i].in_offset = in_total; streams[i].in_length = lens[i];
-        streams[i].out_offset = out_total; streams[i].out_capacity = out_caps[i];
-        streams[i].info = infos[i];
-        in_total += (lens[i] + 63) & ~63ull;
-        out_total += (out_caps[i] + 63) & ~63ull;
+        if (lens[i] >= (1ull << 31)) return fail(h, FLACGPU_ERR_UNSUPPORTED, "stream of 2 GiB or more");
+        items[i] = HostItem{bufs[i], lens[i], out_pcm[i], out_caps[i], 0, 0};
     }
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_in, in_total + 64));
-    hipError_t e = hipMalloc((void **)&d_out, out_total + 64);
-    if (e != hipSuccess) { (void)hipFree(d_in); return fail(h, FLACGPU_ERR_NOMEM, "hipMalloc(out)"); }
-    int rc = FLACGPU_OK;
-    hipStream_t st = h->own_stream;
-    for (uint32_t i = 0; i < n_streams && rc == FLACGPU_OK; ++i)
-        if (hipMemcpyAsync(d_in + streams[i].in_offset, bufs[i], lens[i], hipMemcpyHostToDevice, st) != hipSuccess)
-            rc = fail(h, FLACGPU_ERR_DEVICE, "hipMemcpyAsync(H2D)");
-    if (rc == FLACGPU_OK && hipMemsetAsync(d_out, 0, out_total + 64, st) != hipSuccess) rc = fail(h, FLACGPU_ERR_DEVICE, "hipMemsetAsync");
-    if (rc == FLACGPU_OK) rc = flacgpu_decode_batch_device(h, d_in, in_total, d_out, out_total, streams.data(), n_streams, results, st);
-    for (uint32_t i = 0; i < n_streams && rc == FLACGPU_OK; ++i)
-        if (out_caps[i] && hipMemcpyAsync(out_pcm[i], d_out + streams[i].out_offset, out_caps[i], hipMemcpyDeviceToHost, st) != hipSuccess)
-            rc = fail(h, FLACGPU_ERR_DEVICE, "hipMemcpyAsync(D2H)");
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FLACGPU_OK) rc = fail(h, FLACGPU_ERR_DEVICE, "hipStreamSynchronize");
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    std::vector<flacgpu_stream> streams;
+    flacgpu_timing sum = {};
+    // one chunk of streams: device-resident decode of its arena (offsets are relative to the chunk)
+    auto compute = [&](size_t first, size_t count, uint8_t *d_in, uint64_t in_bytes, uint8_t *d_out, uint64_t out_bytes, hipStream_t st) -> int {
+        streams.resize(count);
+        for (size_t k = 0; k < count; ++k) {
+            flacgpu_stream &s = streams[k];
+            s.in_offset = items[first + k].in_off; s.in_length = lens[first + k];
+            s.out_offset = items[first + k].out_off; s.out_capacity = out_caps[first + k];
+            s.info = infos[first + k];
+        }
+        const int rc = decode_device(h, d_in, std::max<uint64_t>(in_bytes, 16), d_out, out_bytes, streams.data(), (uint32_t)count,
+                                     results ? results + first : nullptr, st);
+        const flacgpu_timing &t = h->timing;
+        sum.scan_ms += t.scan_ms; sum.compact_ms += t.compact_ms; sum.crc16_ms += t.crc16_ms; sum.resolve_ms += t.resolve_ms;
+        sum.skim_ms += t.skim_ms; sum.decode_ms += t.decode_ms; sum.results_ms += t.results_ms; sum.total_ms += t.total_ms;
+        sum.candidates += t.candidates; sum.in_bytes += t.in_bytes; sum.out_bytes += t.out_bytes; sum.decode_classes |= t.decode_classes;
+        return rc;
+    };
+    const int rc = run_staged(h, *host_pipe(h), items, h->own_stream, true, compute, [&](size_t i) { return out_caps[i]; });
+    h->timing = sum;   // device time of all chunks
     return rc;
 }
 

@@ -8,6 +8,7 @@
 // with the optional MD5 kernel beside them on a second stream.  Nothing is read back in between:
 // frame sizes, offsets and stereo decisions stay on the device.
 #include "handle.hpp"
+#include "host_stage.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -342,33 +343,30 @@ int flacgpu_encode_batch(flacgpu_handle *h, const uint8_t *const *pcm, const fla
 {
     if (!h || !pcm || !streams || !n_streams || !opts || !out || !out_caps || !results) return fail(h, FLACGPU_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    std::vector<flacgpu_pcm_stream> ss(streams, streams + n_streams);
-    std::vector<uint64_t> in_len(n_streams);
-    uint64_t in_total = 0, out_total = 0;
+    std::vector<HostItem> items(n_streams);
     for (uint32_t i = 0; i < n_streams; ++i) {
-        in_len[i] = ss[i].total_samples * ss[i].channels * ((ss[i].bits_per_sample + 7) / 8);
-        ss[i].in_offset = in_total; ss[i].out_offset = out_total; ss[i].out_capacity = out_caps[i];
-        in_total += (in_len[i] + 255) & ~255ull;
-        out_total += (out_caps[i] + 255) & ~255ull;
+        const uint64_t len = streams[i].total_samples * streams[i].channels * ((streams[i].bits_per_sample + 7) / 8);
+        items[i] = HostItem{pcm[i], len, out[i], out_caps[i], 0, 0};
     }
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_in, in_total + 256));
-    if (hipMalloc((void **)&d_out, out_total + 256) != hipSuccess) { (void)hipFree(d_in); return fail(h, FLACGPU_ERR_NOMEM, "hipMalloc(out)"); }
-    int rc = FLACGPU_OK;
-    hipStream_t st = h->own_stream;
-    for (uint32_t i = 0; i < n_streams && rc == FLACGPU_OK; ++i)
-        if (in_len[i] && hipMemcpyAsync(d_in + ss[i].in_offset, pcm[i], in_len[i], hipMemcpyHostToDevice, st) != hipSuccess)
-            rc = fail(h, FLACGPU_ERR_DEVICE, "hipMemcpyAsync(H2D)");
-    if (rc == FLACGPU_OK)
-        rc = flacgpu_encode_batch_device(h, d_in, in_total + 256, d_out, out_total + 256, ss.data(), n_streams, opts, results, st);
-    for (uint32_t i = 0; i < n_streams && rc == FLACGPU_OK; ++i) {
-        if (results[i].status != FLACGPU_OK) continue;
-        if (hipMemcpyAsync(out[i], d_out + ss[i].out_offset, results[i].out_length, hipMemcpyDeviceToHost, st) != hipSuccess)
-            rc = fail(h, FLACGPU_ERR_DEVICE, "hipMemcpyAsync(D2H)");
-    }
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FLACGPU_OK) rc = fail(h, FLACGPU_ERR_DEVICE, "hipStreamSynchronize");
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    std::vector<flacgpu_pcm_stream> ss;
+    flacgpu_encode_timing sum = {};
+    auto compute = [&](size_t first, size_t count, uint8_t *d_in, uint64_t in_bytes, uint8_t *d_out, uint64_t out_bytes, hipStream_t st) -> int {
+        ss.assign(streams + first, streams + first + count);
+        for (size_t k = 0; k < count; ++k) {
+            ss[k].in_offset = items[first + k].in_off; ss[k].out_offset = items[first + k].out_off;
+            ss[k].out_capacity = out_caps[first + k];
+        }
+        const int rc = flacgpu_encode_batch_device(h, d_in, in_bytes + 256, d_out, out_bytes + 256, ss.data(), (uint32_t)count, opts,
+                                                   results + first, st);
+        const flacgpu_encode_timing &t = h->enc_timing;
+        sum.stats_ms += t.stats_ms; sum.design_ms += t.design_ms; sum.choose_ms += t.choose_ms; sum.layout_ms += t.layout_ms;
+        sum.pack_ms += t.pack_ms; sum.crc_ms += t.crc_ms; sum.md5_ms += t.md5_ms; sum.total_ms += t.total_ms;
+        sum.frames += t.frames; sum.in_bytes += t.in_bytes; sum.out_bytes += t.out_bytes;
+        return rc;
+    };
+    const int rc = run_staged(h, *host_pipe(h), items, h->own_stream, false, compute,
+                              [&](size_t i) { return results[i].status == FLACGPU_OK ? results[i].out_length : 0ull; });
+    h->enc_timing = sum;
     return rc;
 }
 

@@ -18,6 +18,8 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+struct HostPipe;   // host_stage.hpp: pinned staging buffers and copy streams of the host-buffer entry points
+
 enum { EV_START, EV_SCAN, EV_COMPACT, EV_CRC, EV_RESOLVE, EV_SKIM, EV_DECODE, EV_RESULTS, EV_COUNT };
 enum { EE_START, EE_STATS, EE_DESIGN, EE_CHOOSE, EE_LAYOUT, EE_PACK, EE_CRC, EE_END, EE_MD5_START, EE_MD5_END, EE_COUNT };
 
@@ -36,6 +38,7 @@ struct flacgpu_handle {
     flacgpu_timing timing = {};
     std::vector<flacgpu::StreamDev> h_streams;
     std::vector<flacgpu::ResultDev> h_results;
+    flacgpu::HostPipe *pipe = nullptr;   // created by the first host-buffer call
     bool fixed = false;    // buffers are carved from a static workspace: never freed, never grown
     uint32_t n_cand = 0;   // state of the last scan, used by flacgpu_scan_frames
     // encode
@@ -83,6 +86,10 @@ inline void release(DevBuf &b)
 // decoder (defined in flacgpu.hip).  base must be readable in whole 16-byte vectors around every span.
 __attribute__((visibility("hidden"))) void launch_crc16_spans(flacgpu_handle *h, const uint8_t *base, const uint64_t *off,
                                                               const uint32_t *len, uint16_t *crc, uint32_t n, hipStream_t st);
+
+// The handle's staging pipeline, created on first use / freed (defined in flacgpu.hip).
+__attribute__((visibility("hidden"))) HostPipe *host_pipe(flacgpu_handle *h);
+__attribute__((visibility("hidden"))) void host_pipe_release(flacgpu_handle *h);
 
 // Frees the encoder's part of a handle (defined in flacgpu_encode.hip).
 __attribute__((visibility("hidden"))) void encode_release(flacgpu_handle *h);

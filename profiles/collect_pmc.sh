@@ -3,7 +3,7 @@
 # run; each run holds at most 8 SQ or 4 TCC counters.  Output: gpurun_out/pmc_<tag>/ and .txt summaries.
 set -e
 export TMPDIR=/tmp
-ARGS="bench.py --files ${PMC_FILES:-2000} --unique ${PMC_UNIQUE:-256} --steps ${PMC_STEPS:-2} --warmup 1 --cpu-files 0 --encode-steps ${PMC_ENC_STEPS:-0} ${PMC_EXTRA:-}"
+ARGS="bench.py --files ${PMC_FILES:-2000} --unique ${PMC_UNIQUE:-256} --steps ${PMC_STEPS:-2} --warmup 1 --cpu-files 0 --host-files 0 --encode-steps ${PMC_ENC_STEPS:-0} ${PMC_EXTRA:-}"
 pass() {
     tag=$1; shift
     timeout -s KILL 400 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -o p -- python3 $ARGS > gpurun_out/pmc_$tag.log 2>&1

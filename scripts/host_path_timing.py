@@ -26,7 +26,7 @@ def main():
         infos.append(si)
         audios.append(a)
     eng = flac_amd.Decoder(0, timing=True)
-    eng.decode_batch(audios[:4], infos[:4])           # warm-up
+    eng.decode_batch(audios, infos)                   # warm-up at full size: staging buffers and device arenas grow once
     t0 = time.perf_counter()
     pcms, res = eng.decode_batch(audios, infos)
     t_dec = time.perf_counter() - t0
@@ -35,7 +35,7 @@ def main():
     values = n * nsamples * 2
     shapes = [(nsamples, 44100, 2, 16, bytes(si.md5)) for si in infos]
     opts = flac_amd.encode_options(4096, 12)
-    eng.encode_batch(pcms[:4], shapes[:4], opts)
+    eng.encode_batch(pcms, shapes, opts)
     t0 = time.perf_counter()
     outs, eres = eng.encode_batch(pcms, shapes, opts)
     t_enc = time.perf_counter() - t0

@@ -53,7 +53,7 @@ def test_two_ranks_started_by_bench_itself():
     env["FLAC_BENCH_REHEARSE"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--files", "24", "--unique", "4",
                         "--seconds", "2", "--steps", "2", "--warmup", "1", "--cpu-files", "2", "--cpu-seconds", "0.2",
-                        "--encode-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
+                        "--encode-steps", "1", "--host-files", "6"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -61,4 +61,5 @@ def test_two_ranks_started_by_bench_itself():
     assert out["n_gpus"] == 2 and len(out["rank_ms_per_step"]) == 2 and out["scaling"] == "weak"
     assert out["config"]["files_per_gpu"] == 24 and out["value"] > 0
     assert 0 < out["roofline"]["pipeline_frac"] <= out["roofline"]["frac"] < 1
+    assert out["pcie_inclusive"]["files"] == 6 and 0 < out["pcie_inclusive"]["value"] < out["value"]
     assert out["cpu_baseline"]["cores"] >= 1 and out["host"]["cpu_count"] >= 1 and out["device"]["compute_units"] > 0
