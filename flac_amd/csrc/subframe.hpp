@@ -680,18 +680,24 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     uint32_t dc_rmask[NIT] = {};
     uint32_t dc_half2[NIT] = {}, dc_lmul2[NIT] = {}, dc_rmul2[NIT] = {};   // the same in both 16-bit halves of a word
     bool row16[NIT] = {};   // the frame's rows of four words start on 16-byte boundaries
-    // Other layouts: a frame's 16 samples x C channels are 16C sample slots in output order; a work item is
-    // four consecutive slots of one frame (= B output dwords), 4C items per frame, item = 64 * it + lane,
-    // it = 0 .. 3.  Divisions by C and 4C are multiplications by rounded-up 16-bit reciprocals (exact while
-    // dividend x divisor < 2^16; dividends here are below 256, divisors at most 32).
+    // Other layouts: a frame's 16 samples x C channels are 16C sample slots in output order.  A lane's work
+    // item is sixteen consecutive slots of one frame = 16 B output bytes = B stores of 16 bytes: a frame has C
+    // items, the wave F * C <= 64 of them, lane = f * C + g.  (Four stores of B dwords per lane, four slots
+    // each, cost the 24-bit 8-channel shape a sixth of its time: the wave's store instructions queue.)
+    // Divisions by C and 4C are multiplications by rounded-up 16-bit reciprocals (exact while dividend x
+    // divisor < 2^16; dividends here are below 256, divisors at most 32).
     const uint32_t inv_c = 65536u / C + 1, inv_4c = 65536u / (4 * C) + 1;
-    // What never changes from one write-out to the next is worked out once per item: the LDS addresses of
-    // its four slots (the block's LDS is below 64 KiB), where its dwords go (offset from p.out of the frame's
-    // first tile), and in one word the frame's block size (bits 0-19; 0 for an item beyond the wave's
-    // frames), the sample column of its last slot (20-23) and the channel assignment (24-27).
+    // What never changes from one write-out to the next is worked out once: the LDS addresses of the item's
+    // slots (the block's LDS is below 64 KiB), where its bytes go (offset from p.out of the frame's first
+    // tile), and in one word the frame's block size (bits 0-19; 0 for a lane beyond the wave's frames), the
+    // sample column of its last slot (20-23) and the channel assignment (24-27).
     typedef __attribute__((address_space(3))) const uint32_t lds_word;
-    uint32_t q_src[4][4] = {};
-    uint64_t q_dst[4] = {};
+    // Rows shorter than a 128-byte line (C * B < 8: mono, 8-bit and 24-bit stereo ...) keep the finer mapping
+    // instead: an item is four slots (B dwords, one store), 4C items per frame, item = 64 * it + lane, it = 0 .. 3,
+    // so that one store instruction covers whole rows of consecutive frames rather than a sliver of every row.
+    const bool wide_items = C * B >= 8;
+    uint32_t q_src[16] = {};      // wide: the item's sixteen slots; else [it * 4 + j]
+    uint64_t q_dst[4] = {};       // wide: [0] only
     uint32_t q_meta[4] = {};
     if (STEREO16) {
 #pragma unroll
@@ -713,22 +719,39 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
         }
     } else {
         const uint32_t tile_lds = (uint32_t)(uintptr_t)(lds_word *)tile_raw;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const uint32_t item = it * 64 + lane, f = (item * inv_4c) >> 16, g = item - f * 4 * C;
+        if (wide_items) {
+            const uint32_t f = fl, g = ch;          // this lane's item belongs to the frame it decodes a channel of
             const bool ok = f < F;
             uint32_t col = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t slot = 4 * g + j;
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t slot = 16 * g + j;
                 col = (slot * inv_c) >> 16;
-                q_src[it][j] = tile_lds + (ok ? (col * kRawStride + f * C + (slot - col * C)) * 4 : 0u);
+                q_src[j] = tile_lds + (ok ? (col * kRawStride + f * C + (slot - col * C)) * 4 : 0u);
             }
             const uint32_t fc = ok ? f : 0u;
             const uint64_t dst_f = frame_dst(fc);
             const uint32_t meta = frame_meta(fc);
-            q_dst[it] = ok ? dst_f + g * 4 * B : 0;
-            q_meta[it] = ok ? (meta & 0xFFFFFu) | (col << 20) | (((meta >> 20) & 15u) << 24) : 0u;
+            q_dst[0] = ok ? dst_f + g * 16 * B : 0;
+            q_meta[0] = ok ? (meta & 0xFFFFFu) | (col << 20) | (((meta >> 20) & 15u) << 24) : 0u;
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const uint32_t item = it * 64 + lane, f = (item * inv_4c) >> 16, g = item - f * 4 * C;
+                const bool ok = f < F;
+                uint32_t col = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t slot = 4 * g + j;
+                    col = (slot * inv_c) >> 16;
+                    q_src[it * 4 + j] = tile_lds + (ok ? (col * kRawStride + f * C + (slot - col * C)) * 4 : 0u);
+                }
+                const uint32_t fc = ok ? f : 0u;
+                const uint64_t dst_f = frame_dst(fc);
+                const uint32_t meta = frame_meta(fc);
+                q_dst[it] = ok ? dst_f + g * 4 * B : 0;
+                q_meta[it] = ok ? (meta & 0xFFFFFu) | (col << 20) | (((meta >> 20) & 15u) << 24) : 0u;
+            }
         }
     }
 
@@ -991,45 +1014,93 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             }
             widemask = widemask_rest;
         } else {
-            // the 4 * B output bytes of four slots as dwords d0 .. d(B-1); B == 4: the slots themselves
+            // four 24-bit samples as three dwords
             auto pack = [&](const uint32_t (&v)[4], uint32_t &d0, uint32_t &d1, uint32_t &d2) {
-                if (B == 1) d0 = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
-                if (B == 2) { d0 = (v[0] & 0xFFFFu) | (v[1] << 16); d1 = (v[2] & 0xFFFFu) | (v[3] << 16); }
-                if (B == 3) {
-                    d0 = (v[0] & 0xFFFFFFu) | (v[1] << 24);
-                    d1 = ((v[1] >> 8) & 0xFFFFu) | (v[2] << 16);
-                    d2 = ((v[2] >> 16) & 0xFFu) | (v[3] << 8);
-                }
+                d0 = (v[0] & 0xFFFFFFu) | (v[1] << 24);
+                d1 = ((v[1] >> 8) & 0xFFFFu) | (v[2] << 16);
+                d2 = ((v[2] >> 16) & 0xFFu) | (v[3] << 8);
             };
-            // Items whose four slots all exist in the frame and whose destination is dword aligned (all but a
-            // block's ragged last tile): everything about them but t0 was worked out before the sample loop.
+            // An item whose slots all exist in the frame and whose destination is dword aligned (all but a
+            // block's ragged last tile): everything about it but t0 was worked out before the sample loop.
             bool ragged = false;
+            if (wide_items) {
+                const uint32_t fbs_f = q_meta[0] & 0xFFFFFu;
+                if (t0 < fbs_f) {
+                    if (!dwords || ((q_meta[0] >> 20) & 15u) >= fbs_f - t0) ragged = true;
+                    else {
+                        uint32_t v[16];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const uint32_t fbs_f = q_meta[it] & 0xFFFFFu;
-                if (t0 >= fbs_f) continue;
-                if (!dwords || ((q_meta[it] >> 20) & 15u) >= fbs_f - t0) { ragged = true; continue; }
-                uint32_t v[4];
+                        for (int j = 0; j < 16; ++j) v[j] = *(lds_word *)(uintptr_t)q_src[j];
+                        if (C == 2) {
+                            const uint32_t m = q_meta[0] >> 24;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = *(lds_word *)(uintptr_t)q_src[it][j];
-                if (C == 2) {
-                    const uint32_t m = q_meta[it] >> 24;
-                    uint32_t L, R;
-                    decorrelate(m, v[0], v[1], L, R); v[0] = L; v[1] = R;
-                    decorrelate(m, v[2], v[3], L, R); v[2] = L; v[3] = R;
-                }
-                uint32_t d0 = v[0], d1 = v[1], d2 = v[2];
-                pack(v, d0, d1, d2);
-                // one store per item: multi-dword global stores need dword alignment only, and a wave's stores
-                // count against the same counter as its refill loads, so fewer of them wait less
-                uint8_t *q = p.out + q_dst[it] + (uint64_t)t0 * CB;
+                            for (int j = 0; j < 16; j += 2) {
+                                uint32_t L, R;
+                                decorrelate(m, v[j], v[j + 1], L, R); v[j] = L; v[j + 1] = R;
+                            }
+                        }
+                        // multi-dword global stores need dword alignment only; a wave's stores count against the
+                        // same counter as its refill loads, so fewer and wider ones wait less
+                        uint8_t *q = p.out + q_dst[0] + (uint64_t)t0 * CB;
 #ifdef FLACGPU_DEBUG_NO_STORE
-                if (t0 != 0xFFFFFFF0u) continue;   // ablation build: what the stores of this path cost
+                        if (t0 != 0xFFFFFFF0u) q = nullptr;   // ablation build: what the stores of this path cost
+                        if (q)
 #endif
-                if (B == 1) *reinterpret_cast<uint32_t *>(q) = d0;
-                else if (B == 2) *reinterpret_cast<Dwords2 *>(q) = Dwords2{d0, d1};
-                else if (B == 3) *reinterpret_cast<Dwords3 *>(q) = Dwords3{d0, d1, d2};
-                else *reinterpret_cast<Dwords4 *>(q) = Dwords4{d0, d1, d2, v[3]};
+                        {
+                            if (B == 4) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    reinterpret_cast<Dwords4 *>(q)[k] = Dwords4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+                            } else if (B == 3) {
+                                uint32_t d[12];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const uint32_t w[4] = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+                                    pack(w, d[3 * k], d[3 * k + 1], d[3 * k + 2]);
+                                }
+#pragma unroll
+                                for (int k = 0; k < 3; ++k)
+                                    reinterpret_cast<Dwords4 *>(q)[k] = Dwords4{d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]};
+                            } else if (B == 2) {
+                                uint32_t d[8];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) d[k] = (v[2 * k] & 0xFFFFu) | (v[2 * k + 1] << 16);
+                                reinterpret_cast<Dwords4 *>(q)[0] = Dwords4{d[0], d[1], d[2], d[3]};
+                                reinterpret_cast<Dwords4 *>(q)[1] = Dwords4{d[4], d[5], d[6], d[7]};
+                            } else {
+                                uint32_t d[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    d[k] = (v[4 * k] & 0xFFu) | ((v[4 * k + 1] & 0xFFu) << 8) | ((v[4 * k + 2] & 0xFFu) << 16) | (v[4 * k + 3] << 24);
+                                *reinterpret_cast<Dwords4 *>(q) = Dwords4{d[0], d[1], d[2], d[3]};
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const uint32_t fbs_f = q_meta[it] & 0xFFFFFu;
+                    if (t0 >= fbs_f) continue;
+                    if (!dwords || ((q_meta[it] >> 20) & 15u) >= fbs_f - t0) { ragged = true; continue; }
+                    uint32_t v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = *(lds_word *)(uintptr_t)q_src[it * 4 + j];
+                    if (C == 2) {
+                        const uint32_t m = q_meta[it] >> 24;
+                        uint32_t L, R;
+                        decorrelate(m, v[0], v[1], L, R); v[0] = L; v[1] = R;
+                        decorrelate(m, v[2], v[3], L, R); v[2] = L; v[3] = R;
+                    }
+                    uint8_t *q = p.out + q_dst[it] + (uint64_t)t0 * CB;
+#ifdef FLACGPU_DEBUG_NO_STORE
+                    if (t0 != 0xFFFFFFF0u) continue;
+#endif
+                    if (B == 1) *reinterpret_cast<uint32_t *>(q) = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
+                    else if (B == 2) *reinterpret_cast<Dwords2 *>(q) = Dwords2{(v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16)};
+                    else if (B == 3) { uint32_t d0, d1, d2; pack(v, d0, d1, d2); *reinterpret_cast<Dwords3 *>(q) = Dwords3{d0, d1, d2}; }
+                    else *reinterpret_cast<Dwords4 *>(q) = Dwords4{v[0], v[1], v[2], v[3]};
+                }
             }
             if (__any(ragged))
 #pragma unroll 1
@@ -1042,7 +1113,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 const uint32_t fbs_f = meta & 0xFFFFFu;
                 if (t0 >= fbs_f) continue;
                 const uint32_t ncols = min(kTile, fbs_f - t0);   // sample columns of this tile that exist in the frame
-                if (dwords && ((4 * g + 3) * inv_c >> 16) < ncols) continue;   // written above
+                if (dwords && (((wide_items ? 16 * (g >> 2) + 15 : 4 * g + 3) * inv_c) >> 16) < ncols) continue;   // its item was written above
                 uint32_t v[4], nvalid = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
