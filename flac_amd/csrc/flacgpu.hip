@@ -377,14 +377,17 @@ static int decode_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
         k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C), st>>>(p); p.check_flag = 1
         // the first launch classifies every wave, so it is the class most waves of such streams fall in
         if (r.C == 2 && r.B == 2) {
-            FLACGPU_LAUNCH(12, 3, true); FLACGPU_LAUNCH(32, 3, true); FLACGPU_LAUNCH(12, 0, true); FLACGPU_LAUNCH(32, 0, true);
-            FLACGPU_LAUNCH(12, 1, true); FLACGPU_LAUNCH(32, 1, true); FLACGPU_LAUNCH(12, 2, true); FLACGPU_LAUNCH(32, 2, true);
+            FLACGPU_LAUNCH(12, 3, 1); FLACGPU_LAUNCH(32, 3, 1); FLACGPU_LAUNCH(12, 0, 1); FLACGPU_LAUNCH(32, 0, 1);
+            FLACGPU_LAUNCH(12, 1, 1); FLACGPU_LAUNCH(32, 1, 1); FLACGPU_LAUNCH(12, 2, 1); FLACGPU_LAUNCH(32, 2, 1);
+        } else if (r.C == 1 && r.B == 2) {
+            FLACGPU_LAUNCH(12, 3, 2); FLACGPU_LAUNCH(32, 3, 2); FLACGPU_LAUNCH(12, 0, 0); FLACGPU_LAUNCH(32, 0, 0);
+            FLACGPU_LAUNCH(12, 1, 0); FLACGPU_LAUNCH(32, 1, 0); FLACGPU_LAUNCH(12, 2, 0); FLACGPU_LAUNCH(32, 2, 0);
         } else if (r.B <= 2) {
-            FLACGPU_LAUNCH(12, 3, false); FLACGPU_LAUNCH(32, 3, false); FLACGPU_LAUNCH(12, 0, false); FLACGPU_LAUNCH(32, 0, false);
-            FLACGPU_LAUNCH(12, 1, false); FLACGPU_LAUNCH(32, 1, false); FLACGPU_LAUNCH(12, 2, false); FLACGPU_LAUNCH(32, 2, false);
+            FLACGPU_LAUNCH(12, 3, 0); FLACGPU_LAUNCH(32, 3, 0); FLACGPU_LAUNCH(12, 0, 0); FLACGPU_LAUNCH(32, 0, 0);
+            FLACGPU_LAUNCH(12, 1, 0); FLACGPU_LAUNCH(32, 1, 0); FLACGPU_LAUNCH(12, 2, 0); FLACGPU_LAUNCH(32, 2, 0);
         } else {
-            FLACGPU_LAUNCH(12, 0, false); FLACGPU_LAUNCH(32, 0, false); FLACGPU_LAUNCH(12, 1, false); FLACGPU_LAUNCH(32, 1, false);
-            FLACGPU_LAUNCH(12, 2, false); FLACGPU_LAUNCH(32, 2, false); FLACGPU_LAUNCH(12, 3, false); FLACGPU_LAUNCH(32, 3, false);
+            FLACGPU_LAUNCH(12, 0, 0); FLACGPU_LAUNCH(32, 0, 0); FLACGPU_LAUNCH(12, 1, 0); FLACGPU_LAUNCH(32, 1, 0);
+            FLACGPU_LAUNCH(12, 2, 0); FLACGPU_LAUNCH(32, 2, 0); FLACGPU_LAUNCH(12, 3, 0); FLACGPU_LAUNCH(32, 3, 0);
         }
 #undef FLACGPU_LAUNCH
         if (h->flags & FLACGPU_FLAG_TIMING) k_or_class_flags<<<1, 64, 0, st>>>(p.class_flags, (uint32_t *)h->counter.p + 12);

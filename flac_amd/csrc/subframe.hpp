@@ -565,7 +565,8 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 //            fit 16 bits, which a 17-bit side channel almost always does; a lane that meets one that does
 //            not is rolled back like a lane with an over-long Rice code, and the generic body (24-bit
 //            multiplies) decodes until its history fits again.
-// STEREO16: C == 2 and B == 2, the write-out specialised for it.
+// LAYOUT: 0 = any channel count and sample size (the general write-out); 1 = C == 2 and B == 2 (STEREO16), the
+//         write-out specialised for it; 2 = C == 1 and B == 2 in the 16-bit pair class (MONO16).
 // Lanes stage their samples as coded; stereo decorrelation and packing to the output's sample size happen
 // in the write-out, once per output word.
 //
@@ -575,7 +576,7 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 // moved.  Any other group (warm-up samples, coefficient parsing, partition
 // boundary inside the group, escape-coded or verbatim data, the tail of a block)
 // runs the generic rolled body with a shift-register history.
-template <int NT, int ARITH, bool STEREO16>
+template <int NT, int ARITH, int LAYOUT>
 __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p)   // LDS admits three blocks per CU; the 12-tap classes keep their registers within that
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -585,13 +586,15 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     // seconds of wave time apart, cost the memory system a quarter of the kernel's time).  The unrolled body of
     // that class only keeps samples that fit 16 bits; the few that do not (generic body, 17-bit side channels)
     // are marked in `widemask`, one bit per tile column, and send the write-out down its slow path.
-    constexpr bool TILE16 = STEREO16 && ARITH == 3;
+    constexpr bool STEREO16 = LAYOUT == 1, MONO16 = LAYOUT == 2;
+    static_assert(!MONO16 || ARITH == 3, "the mono layout stages packed 16-bit pairs, which only the 16-bit pair class makes");
+    constexpr bool TILE16 = (STEREO16 && ARITH == 3) || MONO16;
     constexpr uint32_t kT = TILE16 ? 2 * kTile : kTile;
     // The instantiation launched first runs every wave and flags the classes its waves turn out to belong
     // to; the launches that follow are over in microseconds when no wave is theirs.
     constexpr bool DOT = ARITH == 3;
     if (p.check_flag && p.class_flags[(NT == 12 ? 0 : 1) + 2 * ARITH] == 0) return;
-    const uint32_t C = STEREO16 ? 2u : p.C, B = STEREO16 ? 2u : p.B;
+    const uint32_t C = STEREO16 ? 2u : MONO16 ? 1u : p.C, B = (STEREO16 || MONO16) ? 2u : p.B;
     const uint32_t CB = C * B;
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
     const uint32_t F = 64 / C;
@@ -699,7 +702,17 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     uint32_t q_src[16] = {};      // wide: the item's sixteen slots; else [it * 4 + j]
     uint64_t q_dst[4] = {};       // wide: [0] only
     uint32_t q_meta[4] = {};
-    if (STEREO16) {
+    if (MONO16) {
+        // a row is 32 samples = 64 bytes: this lane copies sample columns 8*(lane & 3) .. +7 of frames 16*it + (lane >> 2)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const uint32_t f = it * 16 + (lane >> 2);
+            const uint32_t meta = frame_meta(f);
+            fdst[it] = frame_dst(f) + (lane & 3) * 16;
+            fbs[it] = meta & 0xFFFFFu;
+            row16[it] = dwords && ((reinterpret_cast<uint64_t>(p.out) + fdst[it]) & 15) == 0;
+        }
+    } else if (STEREO16) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const uint32_t f = TILE16 ? it * 8 + (lane >> 3) : it * 16 + (lane >> 2);
@@ -906,7 +919,47 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
         if (t0 != 0xFFFFFFF0u) return;
 #endif
         __builtin_amdgcn_wave_barrier();
-        if (STEREO16) {
+        if (MONO16) {
+            // a word of the tile is two consecutive samples of one frame, the later one in the low half; the
+            // output wants the earlier one there
+            const uint32_t cp4 = (lane & 3) * 4, c8 = (lane & 3) * 8;
+            bool whole = true;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) whole = whole && row16[it] && t0 + c8 + 8 <= fbs[it];
+            if (__all(whole)) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    uint32_t word[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t w = tile_raw[(cp4 + i) * kPairStride + it * 16 + (lane >> 2)];
+                        word[i] = __builtin_amdgcn_alignbit(w, w, 16);
+                    }
+#ifdef FLACGPU_ABL_NOSTORE
+                    if (word[0] == 0x12345678u && word[1] == 0x9abcdef0u && word[2] == word[3])
+#endif
+                    *reinterpret_cast<uint4 *>(p.out + fdst[it] + (uint64_t)t0 * 2) = uint4{word[0], word[1], word[2], word[3]};
+                }
+            } else {
+#pragma unroll 1
+                for (int it = 0; it < NIT; ++it) {
+                    uint64_t dst_it = 0;
+                    uint32_t bs_it = 0;
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k)
+                        if (k == it) { dst_it = fdst[k]; bs_it = fbs[k]; }
+                    uint8_t *at = p.out + dst_it + (uint64_t)t0 * 2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t w = tile_raw[(cp4 + i) * kPairStride + (uint32_t)it * 16 + (lane >> 2)];
+                        const uint32_t n = t0 + c8 + 2 * i;
+                        if (n < bs_it) { at[4 * i] = (uint8_t)(w >> 16); at[4 * i + 1] = (uint8_t)(w >> 24); }
+                        if (n + 1 < bs_it) { at[4 * i + 2] = (uint8_t)w; at[4 * i + 3] = (uint8_t)(w >> 8); }
+                    }
+                }
+            }
+            widemask = widemask_rest;
+        } else if (STEREO16) {
             // four output words (left | right << 16) per lane and row: the lanes of a row write 64 (TILE16: 128)
             // contiguous bytes of one frame
             const uint32_t c4 = (TILE16 ? (lane & 7) : (lane & 3)) * 4;
