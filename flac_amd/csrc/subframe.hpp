@@ -55,6 +55,13 @@ constexpr uint32_t kFetchBelow = kRingWords >= 32 ? 17 : kRingWords - kUnitWords
 #define FLACGPU_SKIM_PAIR_K 9
 #endif
 constexpr uint32_t kSkimPairK = FLACGPU_SKIM_PAIR_K;
+// Compile-time loops: the body gets its index as a std::integral_constant (the unrolled loops index register arrays).
+template <int N, int I = 0, class F>
+__device__ inline void static_for_each(F &&f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_each<N, I + 1>(f); }
+}
+
 
 // a * b + c on the low 24 bits of a and b (sign-extended), low 32 bits of the result: one instruction
 // where a 32-bit multiply and an add are two (both multiplies issue at the full rate on gfx950).  Exact
@@ -896,14 +903,20 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             const uint32_t sum = (s0 + s1) + s2 + (uint32_t)coef[0] * (uint32_t)tap(0);
             return (int32_t)sum >> shift;
         } else {
+            // 16-bit pair class (this is its generic body): the coefficients live packed in cp[] only, which spares
+            // the unrolled body NT registers; here they are taken apart again, tap by tap
+            auto cf = [&](int j) -> int32_t {
+                if constexpr (DOT) return (j & 1) ? (int32_t)cp[j >> 1] >> 16 : __builtin_amdgcn_sbfe((int32_t)cp[j >> 1], 0, 16);
+                else return coef[j];
+            };
             int32_t s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
             for (int j = 1; j < NT; ++j) {
-                if (j % 3 == 1) s0 = mad_i24(coef[j], tap(j), s0);
-                else if (j % 3 == 2) s1 = mad_i24(coef[j], tap(j), s1);
-                else s2 = mad_i24(coef[j], tap(j), s2);
+                if (j % 3 == 1) s0 = mad_i24(cf(j), tap(j), s0);
+                else if (j % 3 == 2) s1 = mad_i24(cf(j), tap(j), s1);
+                else s2 = mad_i24(cf(j), tap(j), s2);
             }
-            const int32_t sum = mad_i24(coef[0], tap(0), (s0 + s1) + s2);
+            const int32_t sum = mad_i24(cf(0), tap(0), (s0 + s1) + s2);
             return sum >> shift;
         }
     };
@@ -1233,9 +1246,17 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
 #pragma unroll
                 for (int m = U - 1; m >= U - NT + 1; m -= 1) pk[m] = pack_lo_hi(ring[m], ring[m - 1]);
             }
-            int32_t s_hist[NT];
+            // what a rolled-back lane needs back: its last NT samples.  The 16-bit pair class keeps them as the NP packs
+            // that hold them (a lane in an unrolled group has a history that fits 16 bits, or it has no residual)
+            int32_t s_hist[DOT ? 1 : NT];
+            uint32_t s_pk[DOT ? NP : 1];
+            if constexpr (DOT) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) s_hist[j] = ring[U - 1 - j];
+                for (int i = 0; i < NP; ++i) s_pk[i] = pk[U - 1 - 2 * i];
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) s_hist[j] = ring[U - 1 - j];
+            }
             uint32_t longest_q = 0;
             bool starved = false;
             uint32_t Q = 0u - br.P;              // the read position, negated (see peek_ring_neg)
@@ -1249,24 +1270,14 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             // the scheduling barrier after the fetch keeps the rest of the sample's instructions behind it.
             uint2 raw = br.fetch_ring_neg(Q);
             uint32_t Qf = Q;
-#pragma unroll
-            for (int P = 0; P < U; ++P) {
-                // Rice code: unary part = leading zeros of the window, then k low bits.  The code's length
-                // nb = q + 1 + k is kept negated: -nb mod 32 is where the low bits start, and it advances Q.
-                const uint32_t w = BitReader::window_neg(raw, Qf);
-                const uint32_t q = lead_zeros_raw(w);
-                longest_q |= q;
-                const uint32_t neg_nb = neg_k1 - q;
-                Q += neg_nb;
-                if (P + 1 < U) {
-                    raw = br.fetch_ring_neg(Q);
-                    Qf = Q;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const uint32_t low = bfe_mod32(w, neg_nb, k);
-                const int32_t res = unzigzag((q << k) | low);
+            // What follows a sample's Rice code u (the zigzag-coded residual): prediction, history, staging, and the
+            // refill round or write-out that falls behind sample P.  PC: P as a compile-time constant.
+            uint32_t *const tile_group = tile_raw + ((n0 & (kT - 1)) >> 1) * kPairStride + lane;   // TILE16: this lane's first pair of the group
+            auto finish_sample = [&](auto PC, uint32_t u) {
+                constexpr int P = decltype(PC)::value;
+                const int32_t res = unzigzag(u);
                 int32_t pred;
-                if (DOT) {
+                if constexpr (DOT) {
                     // pair i = taps 2i and 2i + 1 = samples n - 1 - 2i and n - 2 - 2i = pk[(n - 1 - 2i) % U]; two chains,
                     // and the pair with the newest sample, the only one that waits for the previous result, last
                     int32_t sa = 0, sb = 0;
@@ -1280,13 +1291,15 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 } else {
                     pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
                 }
-                const int32_t v = rice_on ? (int32_t)((uint32_t)res + (uint32_t)pred) : constval;
+                int32_t decoded = (int32_t)((uint32_t)res + (uint32_t)pred);
+                asm volatile("" : "+v"(decoded));   // keeps the arithmetic out of a branch: the select below stays a v_cndmask
+                const int32_t v = rice_on ? decoded : constval;
                 ring[P] = v;
-                if (DOT) pk[P] = pack_lo_hi(v, ring[(P + U - 1) % U]);
+                if constexpr (DOT) pk[P] = pack_lo_hi(v, ring[(P + U - 1) % U]);
                 emit(v, on, ((n0 + (uint32_t)P) & (kT - 1)), std::true_type{});
-                if (TILE16 && (P & 1)) {   // samples P - 1 and P, both known to fit 16 bits if the lane keeps this group
+                if constexpr (TILE16 && (P & 1)) {   // samples P - 1 and P, both known to fit 16 bits if the lane keeps this group
                     const pair16 shifted = __builtin_bit_cast(pair16, pk[P]) << pair16{(short)h.wasted, (short)h.wasted};
-                    tile_raw[(((n0 & (kT - 1)) + (uint32_t)P) >> 1) * kPairStride + lane] = __builtin_bit_cast(uint32_t, shifted);
+                    tile_group[(P >> 1) * kPairStride] = __builtin_bit_cast(uint32_t, shifted);
                 }
                 if ((P + 1) % kRoundSteps == 0 && P + 1 < U) {   // the refill round between samples P and P + 1 (before a write-out, see above)
                     br.P = 0u - Q;
@@ -1294,6 +1307,27 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                     ring_round(br, rf, rice_on);
                 }
                 if (U > (int)kT && P == (int)kT - 1) flush(n0);
+            };
+            // (Two codes per window fetch, as the skim does, were tried here too: one fetch, address and funnel shift
+            // less per pair, but the pair's lengths form a longer dependent chain, and the kernel ran 5 % slower.)
+            {
+                static_for_each<U>([&](auto PC) {
+                    constexpr int P = decltype(PC)::value;
+                    // Rice code: unary part = leading zeros of the window, then k low bits.  The code's length
+                    // nb = q + 1 + k is kept negated: -nb mod 32 is where the low bits start, and it advances Q.
+                    const uint32_t w = BitReader::window_neg(raw, Qf);
+                    const uint32_t q = lead_zeros_raw(w);
+                    longest_q |= q;
+                    const uint32_t neg_nb = neg_k1 - q;
+                    Q += neg_nb;
+                    if (P + 1 < U) {
+                        raw = br.fetch_ring_neg(Q);
+                        Qf = Q;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const uint32_t low = bfe_mod32(w, neg_nb, k);
+                    finish_sample(std::integral_constant<int, P>{}, (q << k) | low);
+                });
             }
             br.P = 0u - Q;
             starved = starved || br.starved();
@@ -1316,7 +1350,10 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 // ring (words come from global memory until the next rounds have refilled it)
                 br.fill = (s_P >> 5) & ~(kUnitWords - 1);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) ring[U - 1 - j] = s_hist[j];
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (DOT) ring[U - 1 - j] = (j & 1) ? (int32_t)s_pk[j >> 1] >> 16 : __builtin_amdgcn_sbfe((int32_t)s_pk[j >> 1], 0, 16);
+                    else ring[U - 1 - j] = s_hist[j];
+                }
             }
         }
         if (run_generic) {
