@@ -43,7 +43,7 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
     import flac_amd
     cap = int(pcm_bytes_per_file * 0.80) // 256 * 256 + 4096     # per-stream output capacity (synthetic ratio is 0.58-0.76)
     nframes = (nsamples + blocksize - 1) // blocksize
-    ncand = 4 if channels == 2 else channels
+    ncand = (4 if args.stereo_mode == -1 else 2) if channels == 2 else channels
     out_bytes = cap * nfiles + 256
     free_b, _ = torch.cuda.mem_get_info(dev)
     need = out_bytes + int(nfiles * nframes * (ncand * (176 + 360) + 96) * 1.15) + (2 << 30)   # output + plans, statistics, frame records
@@ -55,7 +55,7 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
                                    max_partition_order=(args.force_partition_order if args.force_partition_order >= 0
                                                         else args.partition_order),
                                    min_partition_order=max(0, args.force_partition_order),
-                                   force_lpc_order=args.force_lpc_order)
+                                   force_lpc_order=args.force_lpc_order, stereo_mode=args.stereo_mode)
     streams = eng.make_pcm_streams((i * pcm_stride, nsamples, i * cap, cap, rate, channels, bps, bytes(infos[i % unique].md5))
                                    for i in range(nfiles))
     res = eng.encode_batch_device(d_pcm, pcm_stride * nfiles, d_enc, out_bytes, streams, opts, hip_stream=hip_stream)
@@ -83,7 +83,8 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
         ncpu = min(threads, unique, nfiles)
         pcms = [d_pcm[i * pcm_stride: i * pcm_stride + pcm_bytes_per_file].cpu().numpy().tobytes() for i in range(ncpu)]
         oo = oracle.enc_options(blocksize=blocksize, max_lpc_order=args.lpc_order, max_partition_order=opts.max_partition_order,
-                                min_partition_order=opts.min_partition_order, force_lpc_order=args.force_lpc_order)
+                                min_partition_order=opts.min_partition_order, force_lpc_order=args.force_lpc_order,
+                                stereo_mode=args.stereo_mode)
         cpu_s, passes = 0.0, 0
         with ThreadPoolExecutor(max_workers=threads) as ex:   # ctypes releases the GIL inside the C call
             while cpu_s < 0.5 * args.cpu_seconds and passes < 64:
@@ -130,7 +131,7 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
     dom = max(("stats_ms", "choose_ms", "pack_ms"), key=lambda k: kernel_ms[k])
     a_s = kernel_ms[dom] / 1e3
     return {"metric": "encoded PCM samples/sec (per GPU)", "value": values * args.encode_steps / elapsed, "unit": "samples/s",
-            "steps": args.encode_steps, "ms_per_step": elapsed / args.encode_steps * 1e3, "flac_GB": flac_total / 1e9,
+            "stereo_mode": args.stereo_mode, "steps": args.encode_steps, "ms_per_step": elapsed / args.encode_steps * 1e3, "flac_GB": flac_total / 1e9,
             "ratio": flac_total / pcm_total, "algorithmic_GB_per_s": alg * args.encode_steps / elapsed / 1e9,
             "kernel_ms": kernel_ms, "cpu_baseline": cpu_enc, "round_trip_verified": rt,
             "roofline": {"bound": "hbm", "kernel": "k_enc_" + dom[:-3], "achieved": alg / a_s / 1e9 if a_s > 0 else 0.0, "peak": 8000.0,
@@ -248,6 +249,9 @@ def main(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
     ap.add_argument("--host-files", type=int, default=128, help="files decoded through the host-buffer entry point for the PCIe-inclusive rate (0 = skip)")
     ap.add_argument("--encode-steps", type=int, default=2, help="timed steps of the encode leg (0 = skip it)")
+    ap.add_argument("--stereo-mode", type=int, default=-2,
+                    help="encode leg: -2 stereo pair estimated per frame (two channels planned), -1 all four candidate "
+                         "channels planned and the cheapest pair taken, 0..3 one pair for every frame")
     pre = ap.parse_known_args(argv)[0]
     ap.set_defaults(**PRESETS[pre.config])
     args = ap.parse_args(argv)

@@ -20,6 +20,8 @@ FRAME_OK, FRAME_BAD_CRC16, FRAME_BAD_SUBFRAME, FRAME_TRUNCATED, FRAME_LENGTH, FR
     FRAME_SKIPPED = range(8)
 FLAG_TIMING = 1
 ENC_MD5 = 1
+STEREO_EXACT = -1      # flacgpu_encode_options.stereo_mode: all four candidate channels planned, cheapest pair
+STEREO_ESTIMATE = -2   # the pair picked first from short predictors, its two channels planned
 ERR_CAPACITY = 8
 MAX_BLOCKS = 128
 

@@ -61,8 +61,12 @@ struct EncStreamDev {
     uint8_t  channels, bps, bytes_ps, ncand;
     uint8_t  md5[16];
     uint32_t meta_len;        // bytes in front of frame 0: 42, plus 4 + 18 per seek point
-    uint32_t pad[2];
+    int32_t  pair;            // kPairNone: every candidate channel has a plan (ncand of them per frame);
+                              // 0..3: stereo, this channel pair in every frame, two plans per frame;
+                              // kPairEstimated: stereo, the pair of each frame is in EncOptsDev::modes
+    uint32_t pad;
 };
+constexpr int kPairNone = -1, kPairEstimated = 4;
 
 struct EncOptsDev {
     uint32_t blocksize, max_lpc_order, qlp_precision, min_po, max_po;
@@ -71,6 +75,7 @@ struct EncOptsDev {
     uint32_t plan_stride;     // bytes per plan
     uint32_t seek_every;      // frames per seek point, 0 = no SEEKTABLE block
     uint32_t total_units, total_pack, total_frames;
+    uint8_t *modes;           // per frame of a kPairEstimated stream: its channel pair (0..3), written by k_enc_pick
 };
 
 struct PlanHead {             // kPlanHeadBytes
@@ -86,7 +91,8 @@ struct FrameRec {             // 64 bytes
     uint32_t stream;
     uint32_t bs;
     uint8_t  hdr_len, ch_assign;
-    uint8_t  cand[8];         // candidate plan used by each channel
+    uint8_t  cand[8];         // candidate channel coded as each channel (its plan: that candidate's, or the
+                              // channel's own in a stream with two plans per frame)
     uint8_t  pad[2];
     uint32_t sf_bit[8];       // bit offset of each subframe from the frame start
 };
@@ -504,8 +510,16 @@ struct UnitInfo {
     uint32_t f, cand, bs;
     int C, B, cbps;
     bool stereo, last;
+    bool valid;               // false: a padding unit behind the stream's last frame (unit ranges start even)
     const uint8_t *src;
 };
+
+// Candidate channels (0 left, 1 right, 2 mid, 3 side) of the two subframes of a stereo pair
+// (0 left/right, 1 left/side, 2 side/right, 3 mid/side).
+__host__ __device__ inline uint32_t pair_cand(int mode, uint32_t slot)
+{
+    return slot == 0 ? (mode < 2 ? 0u : mode == 2 ? 3u : 2u) : ((mode == 0 || mode == 2) ? 1u : 3u);
+}
 
 __device__ inline UnitInfo unit_info(const uint8_t *pcm, const EncStreamDev *streams, uint32_t n_streams, const uint32_t *hints,
                                      const EncOptsDev &o, uint32_t unit)
@@ -516,6 +530,9 @@ __device__ inline UnitInfo unit_info(const uint8_t *pcm, const EncStreamDev *str
     const uint32_t ncand = u.st->ncand, rel = unit - u.st->unit_begin;
     u.f = rel / ncand;
     u.cand = rel - u.f * ncand;
+    u.valid = u.f < u.st->n_frames;
+    if (u.valid && u.st->pair != kPairNone)
+        u.cand = pair_cand(u.st->pair == kPairEstimated ? (int)o.modes[u.st->frame_begin + u.f] : u.st->pair, u.cand);
     u.last = u.f + 1 == u.st->n_frames;
     u.bs = u.last ? u.st->tail_bs : o.blocksize;
     u.C = u.st->channels; u.B = u.st->bytes_ps;
@@ -544,6 +561,7 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
     const uint32_t unit = unit_base + xcd_unit(blockIdx.x, gridDim.x);
     if (unit >= unit_end) return;
     const UnitInfo u = unit_info(pcm, streams, n_streams, hints, o, unit);
+    if (!u.valid) return;
     const uint32_t bs = u.bs;
     const float *win = windows + (u.last ? u.st->win_off_tail : u.st->win_off);
     CandStats *cs = reinterpret_cast<CandStats *>(stats + (uint64_t)unit * stats_stride(M));
@@ -726,6 +744,170 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
     }
 }
 
+// ---------------------------------------------------------------- pair pick ---
+//
+// Channel pair of every frame of a kPairEstimated stream, before any candidate is analysed, from short
+// linear predictors: the windowed autocorrelation of left, right, mid and side at lags 0..4 in single
+// precision, the prediction error of orders 1..4 (Levinson-Durbin) and from it the estimated size of the
+// subframe; the pair with the smallest sum wins.  The signals are w*l, w*r, (w*l + w*r)/2 and w*l - w*r (the
+// samples as they are, no wasted-bit shift).  Sums are formed per lane over its run of 16 in ascending order
+// with fused multiply-adds, over the 16 lanes of a row by a butterfly, over the rows in ascending order.
+
+template <int NT>
+struct PickShared {
+    float  rs[NT / 16][20];          // per row of 16 lanes: 4 signals x 5 lags
+    float  ac[20];
+    double est[4];
+};
+
+// Left and right samples of the lane's share of a stereo block (see load_block_share).
+template <int NT>
+__device__ inline void load_block_lr(const uint8_t *src, uint32_t bs, int B, int32_t (&l)[kRun], int32_t (&r)[kRun])
+{
+    const uint32_t t = threadIdx.x;
+    if (B == 2) {
+        uint32_t lr[kRun];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t + (uint32_t)j * NT;
+            lr[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)(i < bs ? i : bs - 1) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) { l[j] = (int32_t)(lr[j] << 16) >> 16; r[j] = (int32_t)lr[j] >> 16; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t + (uint32_t)j * NT, ii = i < bs ? i : bs - 1;
+            l[j] = load_le(src + (size_t)(2 * ii) * B, B);
+            r[j] = load_le(src + (size_t)(2 * ii + 1) * B, B);
+        }
+    }
+}
+
+__device__ inline float row_butterfly_f32(float v)
+{
+    v = v + __uint_as_float(dpp_move<FLACGPU_DPP_XOR1>(__float_as_uint(v)));
+    v = v + __uint_as_float(dpp_move<FLACGPU_DPP_XOR2>(__float_as_uint(v)));
+    v = v + __uint_as_float(dpp_move<FLACGPU_DPP_HALF_MIRROR>(__float_as_uint(v)));
+    v = v + __uint_as_float(dpp_move<FLACGPU_DPP_MIRROR>(__float_as_uint(v)));
+    return v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
+                                                 uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
+                                                 const float *__restrict__ windows, uint32_t pair_base, uint32_t pair_end)
+{
+    extern __shared__ __align__(16) int32_t xs[];   // two blocks of enc_lds_words(NT): w*l and w*r, see lds_pos
+    float *xl = reinterpret_cast<float *>(xs), *xr = xl + enc_lds_words(NT);
+    __shared__ PickShared<NT> S;
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint32_t pi = pair_base + xcd_unit(blockIdx.x, gridDim.x);
+    if (pi >= pair_end) return;
+    const uint32_t unit = 2 * pi;                   // unit ranges start even: (frame, first channel of the pair)
+    const EncStreamDev &st = streams[find_enc_stream(streams, n_streams, hints, unit, 0)];
+    if (st.pair != kPairEstimated) return;
+    const uint32_t f = (unit - st.unit_begin) >> 1;
+    if (f >= st.n_frames) return;
+    const bool last = f + 1 == st.n_frames;
+    const uint32_t bs = last ? st.tail_bs : o.blocksize;
+    const int B = st.bytes_ps;
+    const uint8_t *src = pcm + st.in_off + (uint64_t)f * o.blocksize * (uint32_t)(2 * B);
+    const float *win = windows + (last ? st.win_off_tail : st.win_off);
+    {
+        int32_t l[kRun], r[kRun];
+        load_block_lr<NT>(src, bs, B, l, r);
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t + (uint32_t)j * NT;
+            const float w = win[i < bs ? i : 0];
+            const uint32_t at = lds_pos(kFront + i);
+            xl[at] = i < bs ? (float)l[j] * w : 0.0f;
+            xr[at] = i < bs ? (float)r[j] * w : 0.0f;
+        }
+        if (t < lds_lane_base(0)) { xl[t] = 0.0f; xr[t] = 0.0f; }
+    }
+    __syncthreads();
+    {
+        const uint32_t lbase = lds_lane_base(t);
+        float wl[4 + kRun], wr[4 + kRun];
+#pragma unroll
+        for (int m = 0; m < 4 + kRun; ++m) { wl[m] = xl[lbase + lds_rel(m - 4)]; wr[m] = xr[lbase + lds_rel(m - 4)]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x[4 + kRun], acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < 4 + kRun; ++m) x[m] = c == 0 ? wl[m] : c == 1 ? wr[m] : c == 2 ? 0.5f * (wl[m] + wr[m]) : wl[m] - wr[m];
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) acc[q] = __fmaf_rn(x[4 + j], x[4 + j - q], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const float rsum = row_butterfly_f32(acc[q]);
+                if ((lane & 15) == 0) S.rs[t >> 4][c * 5 + q] = rsum;
+            }
+        }
+    }
+    __syncthreads();
+    if (t < 20) {
+        float total = S.rs[0][t];
+        for (int row = 1; row < NT / 16; ++row) total = total + S.rs[row][t];
+        S.ac[t] = total;
+    }
+    __syncthreads();
+    if (t < 4) {
+        // estimated size of the subframe of signal t: the cheapest of orders 1..4 by the rule of k_enc_design
+        const int cbps = (int)st.bps + (t == 3 ? 1 : 0);
+        int prec0 = o.qlp_precision ? (int)o.qlp_precision : default_precision((int)st.bps, bs);
+        prec0 = prec0 > 15 ? 15 : prec0 < 5 ? 5 : prec0;
+        double ac[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ac[q] = (double)S.ac[t * 5 + q];
+        double est = 0.0;
+        if (ac[0] > 0) {
+            const double scale = 0x1.0a6a4c7c29f9ap+0 / (double)bs;   // 0.5 / ln(2)^2 / bs
+            double err = ac[0], tmp[4] = {0.0, 0.0, 0.0, 0.0};
+            bool alive = true, have = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if ((uint32_t)(i + 1) < bs && alive) {
+                    double r = -ac[i + 1];
+#pragma unroll
+                    for (int j = 0; j < i; ++j) r -= tmp[j] * ac[i - j];
+                    if (err <= 0) alive = false;
+                    else {
+                        r /= err;
+                        tmp[i] = r;
+#pragma unroll
+                        for (int j = 0; j < i / 2; ++j) {
+                            const double tj = tmp[j];
+                            tmp[j] += r * tmp[i - 1 - j];
+                            tmp[i - 1 - j] += r * tj;
+                        }
+                        if (i & 1) tmp[i / 2] += tmp[i / 2] * r;
+                        err *= (1.0 - r * r);
+                        const double vv = err * scale;
+                        double bpr = vv > 0 ? 0.5 * est_log2(vv) : 0.0;
+                        if (bpr < 0) bpr = 0;
+                        const double tot = bpr * (double)(bs - (uint32_t)(i + 1)) + (double)(i + 1) * (double)(cbps + prec0);
+                        if (!have || tot < est) { est = tot; have = true; }
+                    }
+                }
+            }
+        }
+        S.est[t] = est;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const double b[4] = {S.est[0] + S.est[1], S.est[0] + S.est[3], S.est[3] + S.est[1], S.est[2] + S.est[3]};
+        int mode = 0;
+        for (int k = 1; k < 4; ++k) if (b[k] < b[mode]) mode = k;
+        o.modes[st.frame_begin + f] = (uint8_t)mode;
+    }
+}
+
 // Levinson-Durbin, order choice and coefficient quantisation: one lane per candidate channel, every array
 // in registers (all loops unrolled, indices known at compile time).
 template <int M>
@@ -735,8 +917,8 @@ __global__ __launch_bounds__(64) void k_enc_design(const EncStreamDev *__restric
     const uint32_t unit = blockIdx.x * 64 + threadIdx.x;
     if (unit >= o.total_units) return;
     CandStats *cs = reinterpret_cast<CandStats *>(stats + (uint64_t)unit * stats_stride(M));
-    if (cs->constant) return;
     const UnitInfo u = unit_info(nullptr, streams, n_streams, hints, o, unit);
+    if (!u.valid || cs->constant) return;
     const uint32_t bs = u.bs;
     uint32_t maxo = o.force_lpc_order ? o.force_lpc_order : o.max_lpc_order;
     if (maxo > (uint32_t)M) maxo = M;
@@ -955,8 +1137,8 @@ __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ p
     const uint32_t unit = unit_base + xcd_unit(blockIdx.x, gridDim.x);
     if (unit >= unit_end) return;
     const CandStats *cs = reinterpret_cast<const CandStats *>(stats + (uint64_t)unit * stats_stride(M));
-    if (cs->constant) return;
     const UnitInfo u = unit_info(pcm, streams, n_streams, hints, o, unit);
+    if (!u.valid || cs->constant) return;
     const uint32_t bs = u.bs;
     uint8_t *plan = plans + (uint64_t)unit * o.plan_stride;
     const int wasted = (int)cs->wasted, sb = u.cbps - wasted;
@@ -1124,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
             fr.stream = blockIdx.x;
             fr.bs = (f + 1 == nf) ? st.tail_bs : o.blocksize;
             if (C == 2) {
-                int mode = o.stereo_mode;
+                int mode = st.pair == kPairNone ? o.stereo_mode : st.pair == kPairEstimated ? (int)o.modes[st.frame_begin + f] : st.pair;
                 if (mode < 0) {
                     const uint32_t b0 = pb[0] + pb[1], b1 = pb[0] + pb[3], b2 = pb[3] + pb[1], b3 = pb[2] + pb[3];
                     mode = 0;
@@ -1133,8 +1315,8 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
                     if (b2 < bb) { bb = b2; mode = 2; }
                     if (b3 < bb) { bb = b3; mode = 3; }
                 }
-                fr.cand[0] = mode == 0 || mode == 1 ? 0 : mode == 2 ? 3 : 2;
-                fr.cand[1] = mode == 0 || mode == 2 ? 1 : 3;
+                fr.cand[0] = (uint8_t)pair_cand(mode, 0);
+                fr.cand[1] = (uint8_t)pair_cand(mode, 1);
                 fr.ch_assign = mode == 0 ? 1 : (uint8_t)(7 + mode);
             } else {
                 for (uint32_t c = 0; c < C; ++c) fr.cand[c] = (uint8_t)c;
@@ -1143,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
             uint8_t hb[16];
             fr.hdr_len = (uint8_t)build_frame_header(hb, fr.bs, st.sample_rate, st.bps, fr.ch_assign, f);
             uint32_t bit = 8u * fr.hdr_len;
-            for (uint32_t c = 0; c < C; ++c) { fr.sf_bit[c] = bit; bit += pb[fr.cand[c]]; }
+            for (uint32_t c = 0; c < C; ++c) { fr.sf_bit[c] = bit; bit += pb[st.pair == kPairNone ? fr.cand[c] : c]; }
             bytes = (bit + 7) / 8 + 2;
             fr.bytes = bytes;
             mn = bytes < mn ? bytes : mn;
@@ -1198,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_enc_layout(EncStreamDev *__restrict__ s
         const uint64_t lo = fr.out_off, hi = lo + fr.bytes;
         const uint8_t *pl = plans + (uint64_t)(st.unit_begin + f * ncand) * o.plan_stride;
         for (uint32_t c = 0; c < C; ++c) {
-            const uint32_t bits = reinterpret_cast<const PlanHead *>(pl + (uint64_t)fr.cand[c] * o.plan_stride)->bits;
+            const uint32_t bits = reinterpret_cast<const PlanHead *>(pl + (uint64_t)(st.pair == kPairNone ? fr.cand[c] : c) * o.plan_stride)->bits;
             const uint64_t gs = lo * 8 + fr.sf_bit[c], ge = gs + bits - 1;
             zero_word_clipped(out, gs >> 5, lo, hi);
             zero_word_clipped(out, ge >> 5, lo, hi);
@@ -1254,7 +1436,7 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
     const FrameRec &fr = frames[st.frame_begin + f];
     if (fr.bytes == 0) return;
     const uint32_t cand = fr.cand[ch], bs = fr.bs, ncand = st.ncand;
-    const uint8_t *plan = plans + (uint64_t)(st.unit_begin + f * ncand + cand) * o.plan_stride;
+    const uint8_t *plan = plans + (uint64_t)(st.unit_begin + f * ncand + (st.pair == kPairNone ? cand : ch)) * o.plan_stride;
     const PlanHead ph = *reinterpret_cast<const PlanHead *>(plan);
     const int B = st.bytes_ps;
     const bool stereo4 = C == 2;

@@ -50,8 +50,18 @@ int encode_init(flacgpu_handle *h)
 template <int M, int NT>
 int launch_analysis(flacgpu_handle *h, uint32_t, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s,
                     uint32_t n, const uint32_t *hints, const EncOptsDev &o, const float *win, uint8_t *stats, uint8_t *plans,
-                    bool timing)
+                    bool timing, bool pick)
 {
+    if (pick) {
+        // channel pair of every frame of the streams that asked for the estimate, before any candidate is analysed
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_pick<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
+        const uint32_t pairs = o.total_units / 2, pchunk = (0xF0000000u / NT) & ~7u;
+        for (uint32_t b = 0; b < pairs; b += pchunk) {
+            const uint32_t e = pairs - b < pchunk ? pairs : b + pchunk;
+            k_enc_pick<NT><<<(e - b + 7) / 8 * 8, NT, 2 * lds, st>>>(pcm, s, n, hints, o, win, b, e);
+        }
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_stats<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_choose<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // a launch holds fewer than 2^32 work-items, so large batches go in several launches
@@ -94,7 +104,7 @@ namespace flacgpu {
 
 void encode_release(flacgpu_handle *h)
 {
-    DevBuf *all[] = {&h->e_streams, &h->e_plans, &h->e_frames, &h->e_crc_off, &h->e_crc_len, &h->e_crc, &h->e_windows, &h->e_md5_T, &h->e_stats, &h->e_hints};
+    DevBuf *all[] = {&h->e_streams, &h->e_plans, &h->e_frames, &h->e_crc_off, &h->e_crc_len, &h->e_crc, &h->e_windows, &h->e_md5_T, &h->e_stats, &h->e_hints, &h->e_modes};
     for (DevBuf *b : all) release(*b);
     for (int i = 0; i < EE_COUNT; ++i)
         if (h->eev[i]) (void)hipEventDestroy(h->eev[i]);
@@ -140,7 +150,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     if (opts->max_partition_order > (uint32_t)kEncMaxPo || opts->min_partition_order > opts->max_partition_order)
         return fail(h, FLACGPU_ERR_ARG, "partition orders must satisfy min <= max <= 8");
     if (opts->qlp_precision && (opts->qlp_precision < 5 || opts->qlp_precision > 15)) return fail(h, FLACGPU_ERR_ARG, "qlp_precision must be 0 or 5..15");
-    if (opts->stereo_mode < -1 || opts->stereo_mode > 3) return fail(h, FLACGPU_ERR_ARG, "stereo_mode must be -1..3");
+    if (opts->stereo_mode < -2 || opts->stereo_mode > 3) return fail(h, FLACGPU_ERR_ARG, "stereo_mode must be -2..3");
     HIP_TRY(hipSetDevice(h->device));
     int rc = encode_init(h);
     if (rc) return rc;
@@ -164,6 +174,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     };
     uint64_t frames = 0, units = 0, pack_units = 0, in_total = 0;
     uint32_t max_bps = 0;
+    bool any_estimated = false;
     for (uint32_t i = 0; i < n_streams; ++i) {
         const flacgpu_pcm_stream &s = streams[i];
         if (s.channels < 1 || s.channels > 8 || s.bits_per_sample < 4 || s.bits_per_sample > 24)
@@ -180,11 +191,17 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
         d.in_off = s.in_offset; d.out_off = s.out_offset; d.out_cap = s.out_capacity; d.total_samples = s.total_samples;
         const uint64_t nf = (s.total_samples + B - 1) / B;
         d.frame_begin = (uint32_t)frames; d.n_frames = (uint32_t)nf;
+        units = (units + 1) & ~1ull;              // unit ranges start even: k_enc_pick takes units in twos
         d.unit_begin = (uint32_t)units; d.pack_begin = (uint32_t)pack_units;
         d.sample_rate = s.sample_rate;
         d.tail_bs = nf ? (uint32_t)(s.total_samples - (nf - 1) * B) : 0;
         d.channels = s.channels; d.bps = s.bits_per_sample; d.bytes_ps = (uint8_t)bytes_ps;
-        d.ncand = s.channels == 2 ? 4 : s.channels;
+        // stereo: four candidate channels with a plan each when the pair is chosen by exact size; two plans
+        // per frame when the pair is known before the analysis (forced, or estimated per frame)
+        d.pair = s.channels != 2 || opts->stereo_mode == FLACGPU_STEREO_EXACT ? kPairNone
+                 : opts->stereo_mode == FLACGPU_STEREO_ESTIMATE ? kPairEstimated : opts->stereo_mode;
+        d.ncand = s.channels == 2 ? (d.pair == kPairNone ? 4 : 2) : s.channels;
+        any_estimated |= d.pair == kPairEstimated;
         d.win_off = window_of(B);
         d.win_off_tail = d.tail_bs ? window_of(d.tail_bs) : d.win_off;
         d.meta_len = 42 + (uint32_t)flacgpu_seektable_bytes(s.total_samples, B, opts->seektable_interval);
@@ -195,6 +212,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
         if (units >= 0x7FFFFFF0ull) return fail(h, FLACGPU_ERR_UNSUPPORTED, "too many subframes in one batch");
         hs[i] = d;
     }
+    units = (units + 1) & ~1ull;
     EncOptsDev o;
     std::memset(&o, 0, sizeof o);
     o.blocksize = B; o.max_lpc_order = opts->max_lpc_order; o.qlp_precision = opts->qlp_precision;
@@ -223,6 +241,8 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
         }
     }
     if ((rc = reserve(h, h->e_hints, hints.size() * 4))) return rc;
+    if ((rc = reserve(h, h->e_modes, (size_t)std::max<uint64_t>(frames, 1)))) return rc;
+    o.modes = (uint8_t *)h->e_modes.p;
     if ((rc = reserve(h, h->e_stats, (size_t)std::max<uint64_t>(units, 1) * stats_stride(M)))) return rc;
     if ((rc = reserve(h, h->e_streams, (size_t)n_streams * sizeof(EncStreamDev)))) return rc;
     if ((rc = reserve(h, h->e_windows, windows.size() * sizeof(float) + 16))) return rc;
@@ -256,10 +276,10 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     uint8_t *plans = (uint8_t *)h->e_plans.p, *stats = (uint8_t *)h->e_stats.p;
     FrameRec *fr = (FrameRec *)h->e_frames.p;
     if (units) {
-        if (M == 12 && NT == 256) rc = launch_analysis<12, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing);
-        else if (M == 32 && NT == 256) rc = launch_analysis<32, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing);
-        else if (M == 12) rc = launch_analysis<12, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing);
-        else rc = launch_analysis<32, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing);
+        if (M == 12 && NT == 256) rc = launch_analysis<12, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated);
+        else if (M == 32 && NT == 256) rc = launch_analysis<32, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated);
+        else if (M == 12) rc = launch_analysis<12, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated);
+        else rc = launch_analysis<32, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated);
         if (rc) return rc;
     } else if (timing) {
         HIP_TRY(hipEventRecord(h->eev[EE_STATS], st)); HIP_TRY(hipEventRecord(h->eev[EE_DESIGN], st)); HIP_TRY(hipEventRecord(h->eev[EE_CHOOSE], st));

@@ -42,7 +42,7 @@ struct flacgpu_handle {
     bool fixed = false;    // buffers are carved from a static workspace: never freed, never grown
     uint32_t n_cand = 0;   // state of the last scan, used by flacgpu_scan_frames
     // encode
-    flacgpu::DevBuf e_streams, e_plans, e_frames, e_crc_off, e_crc_len, e_crc, e_windows, e_md5_T, e_stats, e_hints;
+    flacgpu::DevBuf e_streams, e_plans, e_frames, e_crc_off, e_crc_len, e_crc, e_windows, e_md5_T, e_stats, e_hints, e_modes;
     hipStream_t md5_stream = nullptr;
     hipEvent_t eev[flacgpu::EE_COUNT] = {};
     flacgpu_encode_timing enc_timing = {};

@@ -364,7 +364,7 @@ public:
     // Options of EncodeBatch (flacgpu_encode_options).
     struct EncodeOptions {
         uint32_t BlockSize = 4096, MaxLPCOrder = 12, QLPPrecision = 0, MinPartitionOrder = 0, MaxPartitionOrder = 6;
-        int32_t StereoMode = -1;
+        int32_t StereoMode = FLACGPU_STEREO_EXACT;   // FLACGPU_STEREO_ESTIMATE: about half the analysis work
         uint32_t ForceLPCOrder = 0;
         bool MD5OnDevice = true;
     };

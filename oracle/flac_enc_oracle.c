@@ -373,6 +373,81 @@ static void plan_subframe(const orc_enc_opts *o, const int32_t *sig, uint32_t bs
     if (verb_bits < pl->bits) { pl->type = 1; pl->bits = verb_bits; }   /* also under a forced order */
 }
 
+/* Stereo pair of a frame when stereo_mode is -2, from short linear predictors, before any channel is
+ * planned.  The four signals are w*l, w*r, (w*l + w*r) / 2 and w*l - w*r in single precision (w: the
+ * analysis window; the samples as they are, no wasted-bit shift).  Their autocorrelation at lags 0..4 is
+ * summed in single precision: per lane over its run of 16 in ascending order with fused multiply-adds,
+ * over the 16 lanes of a row by a butterfly (partners at distance 1, 2, 4, 8), over the rows in ascending
+ * order.  Levinson-Durbin in double precision gives the prediction error of orders 1..4 and, by the rule
+ * that picks an LPC order, the estimated size of the subframe; the pair with the smallest sum of sizes
+ * wins, earlier pairs (left/right, left/side, side/right, mid/side) on ties. */
+static int estimate_stereo_mode(const orc_enc_opts *o, int32_t *const sig[4], uint32_t bs, int bps, const float *win)
+{
+    static _Thread_local float x[4][MAX_BS];
+    for (uint32_t i = 0; i < bs; i++) {
+        float wl = (float)sig[0][i] * win[i], wr = (float)sig[1][i] * win[i];
+        x[0][i] = wl; x[1][i] = wr; x[2][i] = 0.5f * (wl + wr); x[3][i] = wl - wr;
+    }
+    const uint32_t lanes = (bs + RUN - 1) / RUN, rows = (lanes + 15) / 16;
+    int prec0 = o->qlp_precision ? (int)o->qlp_precision : default_precision(bps, bs);
+    if (prec0 > 15) prec0 = 15;
+    if (prec0 < 5) prec0 = 5;
+    double est[4];
+    for (int c = 0; c < 4; c++) {
+        double ac[5];
+        for (uint32_t lag = 0; lag < 5; lag++) {
+            float total = 0.0f;
+            for (uint32_t row = 0; row < rows; row++) {
+                float v[16], nv[16];
+                for (uint32_t q = 0; q < 16; q++) {
+                    float a = 0.0f;
+                    for (uint32_t j = 0; j < RUN; j++) {
+                        uint32_t i = (row * 16 + q) * RUN + j;
+                        if (i < bs && i >= lag) a = fmaf(x[c][i], x[c][i - lag], a);
+                    }
+                    v[q] = a;
+                }
+                for (int m = 1; m < 16; m <<= 1) {
+                    for (int q = 0; q < 16; q++) nv[q] = v[q] + v[q ^ m];
+                    memcpy(v, nv, sizeof nv);
+                }
+                total = row ? total + v[0] : v[0];
+            }
+            ac[lag] = (double)total;
+        }
+        const int cbps = bps + (c == 3);
+        double e = 0.0;
+        if (ac[0] > 0) {
+            const double scale = 0x1.0a6a4c7c29f9ap+0 / (double)bs;   /* 0.5 / ln(2)^2 / bs */
+            double err = ac[0], tmp[4] = {0, 0, 0, 0};
+            int have = 0;
+            for (uint32_t i = 0; i < 4 && i + 1 < bs; i++) {
+                double r = -ac[i + 1];
+                for (uint32_t j = 0; j < i; j++) r -= tmp[j] * ac[i - j];
+                if (err <= 0) break;
+                r /= err;
+                tmp[i] = r;
+                for (uint32_t j = 0; j < i / 2; j++) {
+                    double t = tmp[j];
+                    tmp[j] += r * tmp[i - 1 - j];
+                    tmp[i - 1 - j] += r * t;
+                }
+                if (i & 1) tmp[i / 2] += tmp[i / 2] * r;
+                err *= (1.0 - r * r);
+                double v = err * scale, bpr = v > 0 ? 0.5 * est_log2(v) : 0.0;
+                if (bpr < 0) bpr = 0;
+                double tot = bpr * (double)(bs - (i + 1)) + (double)(i + 1) * (double)(cbps + prec0);
+                if (!have || tot < e) { e = tot; have = 1; }
+            }
+        }
+        est[c] = e;
+    }
+    const double b[4] = {est[0] + est[1], est[0] + est[3], est[3] + est[1], est[2] + est[3]};
+    int mode = 0;
+    for (int k = 1; k < 4; k++) if (b[k] < b[mode]) mode = k;
+    return mode;
+}
+
 /* Writes the subframe a plan describes; x: the channel signal before removing wasted bits. */
 static void write_subframe(bw_t *w, const plan_t *pl, const int32_t *sig, uint32_t bs)
 {
@@ -490,8 +565,12 @@ int orc_encode_stream(const uint8_t *pcm, uint64_t total_samples, int channels, 
                 int32_t l = load_sample(src + (size_t)(2 * i) * bytes, bytes), r = load_sample(src + (size_t)(2 * i + 1) * bytes, bytes);
                 sig[0][i] = l; sig[1][i] = r; sig[2][i] = (l + r) >> 1; sig[3][i] = l - r;
             }
-            for (int s = 0; s < 4; s++) plan_subframe(o, sig[s], bs, bps + (s == 3), bps, win, &plans[s]);
+            static const int pick[4][2] = {{0, 1}, {0, 3}, {3, 1}, {2, 3}};
             int mode = o->stereo_mode;
+            if (mode == -2) mode = estimate_stereo_mode(o, sig, bs, bps, win);
+            /* a pair known beforehand: its two channels are planned; -1: all four, the cheapest pair by exact size */
+            for (int s = 0; s < 4; s++)
+                if (mode < 0 || s == pick[mode][0] || s == pick[mode][1]) plan_subframe(o, sig[s], bs, bps + (s == 3), bps, win, &plans[s]);
             if (mode < 0) {
                 uint64_t b0 = plans[0].bits + plans[1].bits, b1 = plans[0].bits + plans[3].bits;
                 uint64_t b2 = plans[3].bits + plans[1].bits, b3 = plans[2].bits + plans[3].bits;
@@ -500,7 +579,6 @@ int orc_encode_stream(const uint8_t *pcm, uint64_t total_samples, int channels, 
                 if (b2 < bb) { bb = b2; mode = 2; }
                 if (b3 < bb) { bb = b3; mode = 3; }
             }
-            static const int pick[4][2] = {{0, 1}, {0, 3}, {3, 1}, {2, 3}};
             static const int assign[4] = {1, 8, 9, 10};
             ch_assign = assign[mode];
             for (int c = 0; c < 2; c++) { use[c] = &plans[pick[mode][c]]; use_sig[c] = sig[pick[mode][c]]; }

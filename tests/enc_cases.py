@@ -31,6 +31,18 @@ ENC_GROUPS = [
          streams=[(2, 16, 22050, 4000)]),
     dict(name="side-right", opts=dict(blocksize=2304, max_lpc_order=12, max_partition_order=5, stereo_mode=2),
          streams=[(2, 16, 44100, 10000)]),
+    # stereo pair estimated per frame (two plans per frame); mono and multichannel streams in the same call
+    dict(name="cd-stereo-lpc12-estimated", opts=dict(blocksize=4096, max_lpc_order=12, max_partition_order=6, stereo_mode=-2),
+         streams=[(2, 16, 44100, 4096 * 4 + 4080), (1, 16, 44100, 4096 * 3), (2, 16, 44100, 4096 * 2), (1, 16, 44100, 10000),
+                  (2, 16, 48000, 17), (2, 24, 96000, 9000), (3, 12, 32000, 4097), (2, 8, 8000, 5000), (2, 16, 44100, 1),
+                  (2, 16, 44100, 0), (2, 4, 8000, 4200), (7, 20, 48000, 4100), (2, 16, 44100, 3)]),
+    dict(name="bs16384-lpc32-estimated", opts=dict(blocksize=16384, max_lpc_order=32, max_partition_order=8, stereo_mode=-2),
+         streams=[(2, 24, 192000, 16384 * 2 + 100), (2, 16, 44100, 16384 + 15), (5, 24, 96000, 20000)]),
+    dict(name="odd-bs-estimated-seektable", opts=dict(blocksize=1000, max_lpc_order=8, max_partition_order=6, stereo_mode=-2,
+                                                       seektable_interval=2),
+         streams=[(2, 16, 44100, 7777), (2, 24, 44100, 3000), (2, 20, 48000, 999)]),
+    dict(name="bs16-estimated", opts=dict(blocksize=16, max_lpc_order=8, max_partition_order=8, stereo_mode=-2),
+         streams=[(2, 16, 44100, 16 * 40 + 3), (2, 24, 44100, 333)]),
 ]
 
 

@@ -57,8 +57,8 @@ def test_oracle_encoder_round_trip(group):
 @pytest.mark.parametrize("kind", SPECIAL_KINDS)
 def test_oracle_encoder_special_signals(kind):
     rng = np.random.default_rng(11)
-    opts = oracle.enc_options(blocksize=1024, max_lpc_order=12, max_partition_order=6)
-    for ch, bps in ((2, 16), (1, 24), (2, 8)):
+    for ch, bps, stereo_mode in ((2, 16, -1), (1, 24, -1), (2, 8, -1), (2, 16, -2), (2, 24, -2)):
+        opts = oracle.enc_options(blocksize=1024, max_lpc_order=12, max_partition_order=6, stereo_mode=stereo_mode)
         n = 1024 * 3 + 333
         x = special_pcm(kind, n, ch, bps, rng)
         packed = synth.pack_pcm(x, bps)
@@ -95,7 +95,7 @@ def random_group(rng):
     order = int(rng.choice([0, 1, 4, 8, 12, 13, 20, 32]))
     max_po = int(rng.integers(0, 9))
     opts = dict(blocksize=bs, max_lpc_order=order, max_partition_order=max_po, min_partition_order=int(rng.integers(0, max_po + 1)),
-                stereo_mode=int(rng.integers(-1, 4)), qlp_precision=int(rng.choice([0, 0, 5, 9, 15])),
+                stereo_mode=int(rng.integers(-2, 4)), qlp_precision=int(rng.choice([0, 0, 5, 9, 15])),
                 force_lpc_order=int(order if order and rng.random() < 0.25 else 0),
                 seektable_interval=int(rng.choice([0, 0, 1, 5])))
     streams = []

@@ -65,10 +65,11 @@ def test_encode_special_signals(decoder):
             x = special_pcm(kind, n, ch, bps, rng)
             packed.append(synth.pack_pcm(x, bps))
             shapes.append((n, 44100, ch, bps))
-    o = dict(blocksize=1024, max_lpc_order=12, max_partition_order=6)
-    gopts = flac_amd.encode_options(flags=flac_amd.ENC_MD5, **o)
-    files, res = gpu_encode_group(decoder, packed, shapes, gopts)
-    _check_against_oracle(files, res, packed, shapes, gopts, oracle.enc_options(**o))
+    for stereo_mode in (flac_amd.STEREO_EXACT, flac_amd.STEREO_ESTIMATE):
+        o = dict(blocksize=1024, max_lpc_order=12, max_partition_order=6, stereo_mode=stereo_mode)
+        gopts = flac_amd.encode_options(flags=flac_amd.ENC_MD5, **o)
+        files, res = gpu_encode_group(decoder, packed, shapes, gopts)
+        _check_against_oracle(files, res, packed, shapes, gopts, oracle.enc_options(**o))
 
 
 def test_encode_then_gpu_decode_round_trip(decoder):
@@ -126,7 +127,7 @@ def test_encode_rejects_bad_arguments(decoder):
     d = torch.zeros(4096, dtype=torch.uint8, device="cuda")
     streams = decoder.make_pcm_streams([(0, 100, 0, 2048, 44100, 2, 16)])
     for bad in (dict(blocksize=8), dict(blocksize=32768), dict(max_lpc_order=33), dict(min_partition_order=5, max_partition_order=4),
-                dict(max_partition_order=9), dict(qlp_precision=3), dict(stereo_mode=7)):
+                dict(max_partition_order=9), dict(qlp_precision=3), dict(stereo_mode=7), dict(stereo_mode=-3)):
         with pytest.raises(flac_amd.FlacError):
             decoder.encode_batch_device(d, 4096, d, 4096, streams, flac_amd.encode_options(**bad))
     for bad_stream in ((0, 100, 0, 2048, 44100, 9, 16), (0, 100, 0, 2048, 44100, 2, 32), (2, 100, 0, 2048, 44100, 2, 16),
