@@ -38,6 +38,10 @@ constexpr int kPlanCoefBytes = 64;   // 32 x int16
 constexpr int kFront = 48;
 __host__ __device__ constexpr uint32_t enc_lds_words(int NT) { return (uint32_t)((kFront + NT * kRun) / kRun * (kRun + 1) + 1); }
 __device__ inline uint32_t lds_pos(uint32_t j) { return j + (j >> 4); }            // j = kFront + sample index
+// Position of sample t + j * NT (the lane's j-th sample as the block is loaded): the lane's first position plus
+// a constant, since NT is a multiple of the run length.
+template <int NT>
+__device__ inline uint32_t lds_share_pos(uint32_t t, int j) { return lds_pos((uint32_t)kFront + t) + (uint32_t)(j * (NT + NT / kRun)); }
 __device__ inline uint32_t lds_lane_base(uint32_t t) { return (uint32_t)(kFront + kFront / kRun) + t * (kRun + 1); }
 // word offset from lds_lane_base of the sample r places after the lane's first one (r may be negative)
 __host__ __device__ constexpr int lds_rel(int r) { return r + (r >= 0 ? r / kRun : -((-r + kRun - 1) / kRun)); }
@@ -367,25 +371,39 @@ __device__ inline int max_partition_order(uint32_t bs, uint32_t order, uint32_t 
 
 // Residual of a fixed predictor, 32-bit wrapping arithmetic.  xs: the block in LDS (see lds_pos), lbase: the
 // lane's run.
+template <int ORDER>
+__device__ inline void fixed_residual_of(const int32_t (&w)[4 + kRun], uint32_t (&u)[kRun])
+{
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+        const uint32_t a = (uint32_t)w[4 + j], b = (uint32_t)w[3 + j], c = (uint32_t)w[2 + j], d = (uint32_t)w[1 + j],
+                       e = (uint32_t)w[j];
+        const uint32_t r = ORDER == 0 ? a : ORDER == 1 ? a - b : ORDER == 2 ? a - 2 * b + c : ORDER == 3 ? a - 3 * b + 3 * c - d
+                                                                                              : a - 4 * b + 6 * c - 4 * d + e;
+        u[j] = fold((int32_t)r);
+    }
+}
 __device__ inline void fixed_residual(const int32_t *xs, uint32_t lbase, int order, uint32_t (&u)[kRun])
 {
     int32_t w[4 + kRun];
 #pragma unroll
     for (int m = 0; m < 4 + kRun; ++m) w[m] = xs[lbase + lds_rel(m - 4)];
-#pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-        const uint32_t a = (uint32_t)w[4 + j], b = (uint32_t)w[3 + j], c = (uint32_t)w[2 + j], d = (uint32_t)w[1 + j],
-                       e = (uint32_t)w[j];
-        uint32_t r;
-        switch (order) {
-        case 0: r = a; break;
-        case 1: r = a - b; break;
-        case 2: r = a - 2 * b + c; break;
-        case 3: r = a - 3 * b + 3 * c - d; break;
-        default: r = a - 4 * b + 6 * c - 4 * d + e; break;
-        }
-        u[j] = fold((int32_t)r);
+    // the order is the same for the whole workgroup: one loop per order
+    switch (order) {
+    case 0: fixed_residual_of<0>(w, u); break;
+    case 1: fixed_residual_of<1>(w, u); break;
+    case 2: fixed_residual_of<2>(w, u); break;
+    case 3: fixed_residual_of<3>(w, u); break;
+    default: fixed_residual_of<4>(w, u); break;
     }
+}
+
+// |a - b| + c on unsigned values, one instruction (the compiler spells __usad as max - min + c).
+__device__ inline uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 __device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
@@ -408,8 +426,8 @@ __device__ inline uint32_t run_mask(uint32_t i0, uint32_t first, uint32_t end)
 // most 15), 1: 32-bit wrapping sums, 2: 64-bit sums.  The taps are taken in passes of at most 16 so that a
 // pass's coefficients, its window of samples and the 16 running sums fit the registers of a 1024-lane
 // workgroup.  The result is nonzero when some residual of the run may not fit 32 bits (r + 2^31 - 1 has bits
-// above 31 exactly when r is outside [-(2^31 - 1), 2^31 - 1]); the caller then finds out which with
-// lpc_residual_bad.
+// above 31 exactly when r is outside [-(2^31 - 1), 2^31 - 1]; MODE 0 has a cheaper test that also reports
+// some residuals that fit); the caller then finds out which with lpc_residual_bad.
 template <int M, int MODE>
 __device__ inline uint32_t lpc_residual(const int32_t *xs, uint32_t lbase, const int32_t *cq, int shift, uint32_t (&u)[kRun])
 {
@@ -453,11 +471,20 @@ __device__ inline uint32_t lpc_residual(const int32_t *xs, uint32_t lbase, const
     asm volatile("" : "+v"(lb2));
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
-        const int64_t pred = MODE == 2 ? (int64_t)acc[j] >> shift : (int64_t)((int32_t)(uint32_t)acc[j] >> shift);
-        const int64_t r = (int64_t)xs[lb2 + j] - pred;
-        high |= (uint32_t)((uint64_t)(r + 0x7FFFFFFFLL) >> 32);
-        u[j] = fold((int32_t)r);
+        if (MODE == 0) {
+            // samples of at most 24 bits: a prediction inside [-2^30, 2^30) leaves a residual that fits with room
+            // to spare; anything else is reported (bit 31 of the sum below) and settled by lpc_residual_bad
+            const int32_t pred = (int32_t)(uint32_t)acc[j] >> shift;
+            high |= (uint32_t)pred + 0x40000000u;
+            u[j] = fold((int32_t)((uint32_t)xs[lb2 + j] - (uint32_t)pred));
+        } else {
+            const int64_t pred = MODE == 2 ? (int64_t)acc[j] >> shift : (int64_t)((int32_t)(uint32_t)acc[j] >> shift);
+            const int64_t r = (int64_t)xs[lb2 + j] - pred;
+            high |= (uint32_t)((uint64_t)(r + 0x7FFFFFFFLL) >> 32);
+            u[j] = fold((int32_t)r);
+        }
     }
+    if (MODE == 0) high &= 0x80000000u;
     return high;
 }
 
@@ -576,11 +603,16 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
     uint32_t ored = 0, neq = 0;
     const int32_t first = cand_sample(u.src, 0, u.C, u.B, (int)u.cand, u.stereo);
     load_block_share<NT>(u.src, bs, u.C, u.B, (int)u.cand, u.stereo, v);
+    if (bs == (uint32_t)(NT * kRun)) {   // the block fills the workgroup's span: no sample to leave out
 #pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-        const uint32_t i = t + (uint32_t)j * NT;
-        ored |= (uint32_t)v[j];
-        neq |= i < bs ? (uint32_t)(v[j] ^ first) : 0u;
+        for (int j = 0; j < kRun; ++j) { ored |= (uint32_t)v[j]; neq |= (uint32_t)(v[j] ^ first); }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            const uint32_t i = t + (uint32_t)j * NT;
+            ored |= (uint32_t)v[j];
+            neq |= i < bs ? (uint32_t)(v[j] ^ first) : 0u;
+        }
     }
     __syncthreads();
     ored = wave_or(ored); neq = wave_or(neq);
@@ -599,7 +631,7 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
         return;
     }
 #pragma unroll
-    for (int j = 0; j < kRun; ++j) xs[lds_pos(kFront + t + (uint32_t)j * NT)] = v[j] >> wasted;
+    for (int j = 0; j < kRun; ++j) xs[lds_share_pos<NT>(t, j)] = v[j] >> wasted;
     if (t < lds_lane_base(0)) xs[t] = 0;
     __syncthreads();
 
@@ -636,14 +668,14 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
                 for (int jj = 0; jj < kRun / 2; ++jj) {
                     const int j = half * (kRun / 2) + jj;
                     const uint32_t c0 = (uint32_t)w[4 + j] ^ Z;
-                    e32[0] = __usad(c0, Z, e32[0]);
-                    e32[1] = __usad(c0, p0, e32[1]);
+                    e32[0] = sad_u32(c0, Z, e32[0]);
+                    e32[1] = sad_u32(c0, p0, e32[1]);
                     const uint32_t c1 = (c0 - p0) ^ Z;
-                    e32[2] = __usad(c1, p1, e32[2]);
+                    e32[2] = sad_u32(c1, p1, e32[2]);
                     const uint32_t c2 = (c1 - p1) ^ Z;
-                    e32[3] = __usad(c2, p2, e32[3]);
+                    e32[3] = sad_u32(c2, p2, e32[3]);
                     const uint32_t c3 = (c2 - p2) ^ Z;
-                    e32[4] = __usad(c3, p3, e32[4]);
+                    e32[4] = sad_u32(c3, p3, e32[4]);
                     p0 = c0; p1 = c1; p2 = c2; p3 = c3;
                 }
 #pragma unroll
@@ -747,16 +779,17 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
 // ---------------------------------------------------------------- pair pick ---
 //
 // Channel pair of every frame of a kPairEstimated stream, before any candidate is analysed, from short
-// linear predictors: the windowed autocorrelation of left, right, mid and side at lags 0..4 in single
-// precision, the prediction error of orders 1..4 (Levinson-Durbin) and from it the estimated size of the
-// subframe; the pair with the smallest sum wins.  The signals are w*l, w*r, (w*l + w*r)/2 and w*l - w*r (the
-// samples as they are, no wasted-bit shift).  Sums are formed per lane over its run of 16 in ascending order
-// with fused multiply-adds, over the 16 lanes of a row by a butterfly, over the rows in ascending order.
+// linear predictors: the windowed autocorrelation of left, right and side at lags 0..4 in single precision
+// (mid's follows from them: side + 4 mid = 2 (left + right) for sums of products), the prediction error of
+// orders 1..4 (Levinson-Durbin) and from it the estimated size of the subframe; the pair with the smallest
+// sum wins.  The signals are w*l, w*r and w*l - w*r (the samples as they are, no wasted-bit shift).  Sums are
+// formed per lane over its run of 16 in ascending order with fused multiply-adds, over the 16 lanes of a row
+// by a butterfly, over the rows in ascending order.
 
 template <int NT>
 struct PickShared {
-    float  rs[NT / 16][20];          // per row of 16 lanes: 4 signals x 5 lags
-    float  ac[20];
+    float  rs[NT / 16][15];          // per row of 16 lanes: left, right, side x 5 lags
+    float  ac[15];
     double est[4];
 };
 
@@ -821,7 +854,7 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
         for (int j = 0; j < kRun; ++j) {
             const uint32_t i = t + (uint32_t)j * NT;
             const float w = win[i < bs ? i : 0];
-            const uint32_t at = lds_pos(kFront + i);
+            const uint32_t at = lds_share_pos<NT>(t, j);
             xl[at] = i < bs ? (float)l[j] * w : 0.0f;
             xr[at] = i < bs ? (float)r[j] * w : 0.0f;
         }
@@ -834,10 +867,10 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
 #pragma unroll
         for (int m = 0; m < 4 + kRun; ++m) { wl[m] = xl[lbase + lds_rel(m - 4)]; wr[m] = xr[lbase + lds_rel(m - 4)]; }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 3; ++c) {
             float x[4 + kRun], acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int m = 0; m < 4 + kRun; ++m) x[m] = c == 0 ? wl[m] : c == 1 ? wr[m] : c == 2 ? 0.5f * (wl[m] + wr[m]) : wl[m] - wr[m];
+            for (int m = 0; m < 4 + kRun; ++m) x[m] = c == 0 ? wl[m] : c == 1 ? wr[m] : wl[m] - wr[m];
 #pragma unroll
             for (int j = 0; j < kRun; ++j) {
 #pragma unroll
@@ -851,7 +884,7 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
         }
     }
     __syncthreads();
-    if (t < 20) {
+    if (t < 15) {
         float total = S.rs[0][t];
         for (int row = 1; row < NT / 16; ++row) total = total + S.rs[row][t];
         S.ac[t] = total;
@@ -864,7 +897,10 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
         prec0 = prec0 > 15 ? 15 : prec0 < 5 ? 5 : prec0;
         double ac[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) ac[q] = (double)S.ac[t * 5 + q];
+        for (int q = 0; q < 5; ++q) {
+            const double al = (double)S.ac[q], ar = (double)S.ac[5 + q], as = (double)S.ac[10 + q];
+            ac[q] = t == 0 ? al : t == 1 ? ar : t == 3 ? as : (2.0 * (al + ar) - as) * 0.25;
+        }
         double est = 0.0;
         if (ac[0] > 0) {
             const double scale = 0x1.0a6a4c7c29f9ap+0 / (double)bs;   // 0.5 / ln(2)^2 / bs
@@ -1158,7 +1194,7 @@ __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ p
         int32_t v[kRun];
         load_block_share<NT>(u.src, bs, u.C, u.B, (int)u.cand, u.stereo, v);
 #pragma unroll
-        for (int j = 0; j < kRun; ++j) xs[lds_pos(kFront + t + (uint32_t)j * NT)] = v[j] >> wasted;
+        for (int j = 0; j < kRun; ++j) xs[lds_share_pos<NT>(t, j)] = v[j] >> wasted;
     }
     if (t < lds_lane_base(0)) xs[t] = 0;
     __syncthreads();
@@ -1453,7 +1489,7 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
         int32_t v[kRun];
         load_block_share<NT>(src, bs, (int)C, B, (int)cand, stereo4, v);
 #pragma unroll
-        for (int j = 0; j < kRun; ++j) xs[lds_pos(kFront + t + (uint32_t)j * NT)] = v[j] >> wasted;
+        for (int j = 0; j < kRun; ++j) xs[lds_share_pos<NT>(t, j)] = v[j] >> wasted;
     }
     if (t < lds_lane_base(0)) xs[t] = 0;
     if (t < 32) s_q[t] = type == 3 ? (int32_t)reinterpret_cast<const int16_t *>(plan + kPlanHeadBytes)[t] : 0;

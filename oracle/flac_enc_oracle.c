@@ -374,27 +374,26 @@ static void plan_subframe(const orc_enc_opts *o, const int32_t *sig, uint32_t bs
 }
 
 /* Stereo pair of a frame when stereo_mode is -2, from short linear predictors, before any channel is
- * planned.  The four signals are w*l, w*r, (w*l + w*r) / 2 and w*l - w*r in single precision (w: the
- * analysis window; the samples as they are, no wasted-bit shift).  Their autocorrelation at lags 0..4 is
- * summed in single precision: per lane over its run of 16 in ascending order with fused multiply-adds,
- * over the 16 lanes of a row by a butterfly (partners at distance 1, 2, 4, 8), over the rows in ascending
- * order.  Levinson-Durbin in double precision gives the prediction error of orders 1..4 and, by the rule
+ * planned.  The signals are w*l, w*r and w*l - w*r in single precision (w: the analysis window; the
+ * samples as they are, no wasted-bit shift).  Their autocorrelation at lags 0..4 is summed in single
+ * precision: per lane over its run of 16 in ascending order with fused multiply-adds, over the 16 lanes
+ * of a row by a butterfly (partners at distance 1, 2, 4, 8), over the rows in ascending order.  Mid's
+ * autocorrelation is taken from those three: side + 4 mid = 2 (left + right).  Levinson-Durbin in double precision gives the prediction error of orders 1..4 and, by the rule
  * that picks an LPC order, the estimated size of the subframe; the pair with the smallest sum of sizes
  * wins, earlier pairs (left/right, left/side, side/right, mid/side) on ties. */
 static int estimate_stereo_mode(const orc_enc_opts *o, int32_t *const sig[4], uint32_t bs, int bps, const float *win)
 {
-    static _Thread_local float x[4][MAX_BS];
+    static _Thread_local float x[3][MAX_BS];       /* left, right, side */
     for (uint32_t i = 0; i < bs; i++) {
         float wl = (float)sig[0][i] * win[i], wr = (float)sig[1][i] * win[i];
-        x[0][i] = wl; x[1][i] = wr; x[2][i] = 0.5f * (wl + wr); x[3][i] = wl - wr;
+        x[0][i] = wl; x[1][i] = wr; x[2][i] = wl - wr;
     }
     const uint32_t lanes = (bs + RUN - 1) / RUN, rows = (lanes + 15) / 16;
     int prec0 = o->qlp_precision ? (int)o->qlp_precision : default_precision(bps, bs);
     if (prec0 > 15) prec0 = 15;
     if (prec0 < 5) prec0 = 5;
-    double est[4];
-    for (int c = 0; c < 4; c++) {
-        double ac[5];
+    double est[4], acs[3][5];
+    for (int c = 0; c < 3; c++) {
         for (uint32_t lag = 0; lag < 5; lag++) {
             float total = 0.0f;
             for (uint32_t row = 0; row < rows; row++) {
@@ -413,8 +412,14 @@ static int estimate_stereo_mode(const orc_enc_opts *o, int32_t *const sig[4], ui
                 }
                 total = row ? total + v[0] : v[0];
             }
-            ac[lag] = (double)total;
+            acs[c][lag] = (double)total;
         }
+    }
+    for (int c = 0; c < 4; c++) {                  /* left, right, mid, side */
+        double ac[5];
+        for (int lag = 0; lag < 5; lag++)
+            ac[lag] = c == 0 ? acs[0][lag] : c == 1 ? acs[1][lag] : c == 3 ? acs[2][lag]
+                      : (2.0 * (acs[0][lag] + acs[1][lag]) - acs[2][lag]) * 0.25;
         const int cbps = bps + (c == 3);
         double e = 0.0;
         if (ac[0] > 0) {
