@@ -200,10 +200,16 @@ def lookup_traffic(tag, kernel, nfiles):
             if pmc.get("workload_tag") != tag or kernel not in pmc["kernels"]:
                 continue
             kd = pmc["kernels"][kernel]
-            traffic = (2.0 * kd["FETCH_SIZE_KiB"] + kd["WRITE_SIZE_KiB"]) * 1024.0 * nfiles / pmc["files"]
-            return traffic, (f"(2 x FETCH_SIZE + WRITE_SIZE) of {kernel} from {os.path.relpath(path, ROOT)}, measured at "
-                             f"{pmc['files']} files of this workload and scaled to {nfiles}; the factor 2 is calibrated for "
-                             f"coalesced reads only and is an upper bound for this kernel's 32-byte sector reads")
+            # read-side correction per kernel family (see the note in the json): 2 for wide coalesced reads, the
+            # calibrated value where the profile states one
+            factor = 2.0
+            for prefix, f in pmc.get("fetch_factor", {}).items():
+                if kernel.startswith(prefix):
+                    factor = float(f)
+            traffic = (factor * kd["FETCH_SIZE_KiB"] + kd["WRITE_SIZE_KiB"]) * 1024.0 * nfiles / pmc["files"]
+            return traffic, (f"({factor:g} x FETCH_SIZE + WRITE_SIZE) of {kernel} from {os.path.relpath(path, ROOT)}, measured at "
+                             f"{pmc['files']} files of this workload and scaled to {nfiles}; read-side factor as calibrated in "
+                             f"that file's note")
         except (OSError, KeyError, ValueError, TypeError):
             continue
     return None, f"no committed counter profile of {kernel} on workload {tag}"
