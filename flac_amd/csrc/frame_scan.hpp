@@ -526,8 +526,13 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
 
     struct Span { uint64_t A; uint32_t lead, npieces, steps, pad, trail; };
+    // a span belongs to the whole wave: its geometry goes through the first lane into scalar registers, so the
+    // step loop and its first-step / last-step cases are scalar branches, not lane masks
+    auto uniform32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     auto geometry = [&](uint64_t a, uint32_t len) {
         Span g;
+        a = ((uint64_t)uniform32((uint32_t)(a >> 32)) << 32) | uniform32((uint32_t)a);
+        len = uniform32(len);
         g.A = a & ~(uint64_t)15;
         g.lead = (uint32_t)(a - g.A);
         const uint32_t total = g.lead + len;
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
         return uint4{w[0], w[1], w[2], w[3]};
     };
 
-    uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t r = uniform32(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (r >= n_cand) return;
     Span g = geometry(c.goff[r], c.seglen[r]);
     uint4 cur = load_piece(g, 0);
@@ -567,13 +572,15 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
         Span g_next = g;
         if (r_next < n_cand) g_next = geometry(c.goff[r_next], c.seglen[r_next]);
         uint32_t acc = 0;
-        for (uint32_t t = 0; t < g.steps; ++t) {
+        const uint32_t steps = uniform32(g.steps);
+        const bool more = uniform32(r_next < n_cand ? 1u : 0u) != 0;
+        for (uint32_t t = 0; t < steps; ++t) {
             uint4 nxt = uint4{0u, 0u, 0u, 0u};
-            if (t + 1 < g.steps) nxt = load_piece(g, t + 1);
-            else if (r_next < n_cand) nxt = load_piece(g_next, 0);
+            if (t + 1 < steps) nxt = load_piece(g, t + 1);
+            else if (more) nxt = load_piece(g_next, 0);
             const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)g.pad;
             if (t == 0 && g.lead && j == 0) cur = keep_bytes(cur, g.lead, 16);
-            if (t + 1 == g.steps && g.trail && j == (int32_t)g.npieces - 1) cur = keep_bytes(cur, 0, 16 - g.trail);
+            if (t + 1 == steps && g.trail && j == (int32_t)g.npieces - 1) cur = keep_bytes(cur, 0, 16 - g.trail);
             const uint32_t pc = crc16_piece(cur);
             acc = skip[acc & 0xFF] ^ skip[256 + (acc >> 8)] ^ pc;
             cur = nxt;

@@ -855,8 +855,10 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     // not an error when it fails, but the group's products were wrong and the lane is redone.
     const uint32_t sbits = h.sbps ? h.sbps : 32u;
     const uint32_t half = 1u << (sbits - 1);
-    const bool pair17 = DOT && h.sbps + h.wasted == 17;
-    const uint32_t fast_bits = pair17 ? 16u - h.wasted : sbits;   // what a sample of an unrolled group has to fit
+    // 17-bit lanes of the pair class: a subframe 17 bits wide after its wasted bits (the packed history holds 16), or
+    // one whose samples are 17 bits wide with their wasted bits (a side channel: the packed tile holds 16)
+    const bool pair17 = DOT && (h.sbps == 17 || h.sbps + h.wasted == 17);
+    const uint32_t fast_bits = pair17 ? sbits - 1 : sbits;   // what a sample of an unrolled group has to fit
     const uint32_t half_fast = pair17 ? ((1u << fast_bits) >> 1) : half;
     uint32_t ovf = 0, govf = 0;
     // TILE16: columns of the current tile whose staged value (sample << wasted bits) does not fit 16 bits.  A

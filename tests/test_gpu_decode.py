@@ -309,6 +309,51 @@ def test_side_channels_wider_than_16_bits(decoder, mode):
         assert np.array_equal(pcm, want)
 
 
+def seventeen_bit_streams():
+    """Streams whose subframes are 17 bits wide once their wasted bits are gone: (file, packed PCM) lists."""
+    rng = np.random.default_rng(1717)
+    files, srcs = [], []
+
+    def add(x, bps, bs=1024, order=12, **kw):
+        f, _ = synth.encode(x.astype(np.int32), bps, 48000, synth.options(bs, order, stereo_mode=0, **kw))
+        files.append(bytes(f))
+        srcs.append(synth.pack_pcm(x.astype(np.int32), bps))
+
+    for bps, ch, n, bs, order, kw in ((24, 1, 1358, 2048, 12, dict(rice_method=1, force_lpc_order=12)), (24, 1, 1024 * 5 + 77, 1024, 12, {}),
+                                      (24, 2, 4096 * 2 + 500, 4096, 32, {}), (20, 5, 1024 * 3 + 9, 1024, 8, {}), (17, 2, 1024 * 4, 1024, 12, {}),
+                                      (24, 2, 1024 * 4 + 3, 1024, 0, {})):
+        wasted = bps - 17
+        t = np.arange(n)
+        for kind in ("wide", "quiet with loud stretches", "wide warm-up"):
+            if kind == "wide":
+                v = (40000 * np.sin(t[:, None] / (9.0 + np.arange(ch)))).astype(np.int64) + rng.integers(-3000, 3000, (n, ch))
+            else:
+                v = (9000 * np.sin(t[:, None] / (7.0 + np.arange(ch)))).astype(np.int64) + rng.integers(-40, 40, (n, ch))
+                if kind == "wide warm-up":
+                    v[:12] = 65535 * (1 - 2 * (np.arange(12)[:, None] & 1))
+                else:
+                    for at in rng.integers(0, n - 40, size=6):
+                        w = int(rng.integers(1, 40))
+                        v[at:at + w] = rng.choice([-65536, 65535])
+            v = np.clip(v, -65536, 65535)
+            add(v << wasted, bps, bs=bs, order=order, **kw)
+    return files, srcs
+
+
+def test_seventeen_bit_subframes_of_wider_streams(decoder):
+    """Subframes that are 17 bits wide once their wasted bits are gone, in 24- and 20-bit streams (and plain 17-bit
+    ones): they decode in the 16-bit pair class, whose packed history holds 16 bits, so a group with a sample that
+    needs the 17th is redone sample by sample.  Quiet streams with loud stretches, streams that are wide
+    throughout, mono / stereo / 5 channels, warm-up samples at full width, 12 and 32 taps, ragged single frames."""
+    files, srcs = seventeen_bit_streams()
+    pcms, res, infos = gpu_batch(decoder, files, out_fill=0x33)
+    for f, pcm, src, si, r in zip(files, pcms, srcs, infos, res):
+        want, ost = oracle_decode(si, split_file(f)[1])
+        assert bytes(want) == src and md5hex(src) == si.md5_signature
+        assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples)
+        assert np.array_equal(pcm, want)
+
+
 def test_full_scale_noise_outruns_the_refill_schedule(decoder):
     """White noise at full scale is incompressible: nearly bps bits per code, so the lanes consume their
     bit-reader rings as fast as the refill rounds can fill them and some run dry inside the unrolled loop
