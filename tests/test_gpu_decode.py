@@ -377,6 +377,40 @@ def test_full_scale_noise_outruns_the_refill_schedule(decoder):
         assert r.frames_ok == ost.frames_ok == 4
 
 
+def test_minutes_of_audio_in_one_batch(decoder):
+    """A batch of whole minutes rather than a few frames (the other tests keep streams short so that the oracle is
+    quick): two minutes of 16-bit stereo in 20 files, 10 s of mono, 1 s of 192 kHz 24-bit 8-channel LPC-32.  Every stream's frame
+    count, sample count and MD5 against STREAMINFO; one stream of each shape against the oracle byte by byte; then
+    the PCM through the GPU encoder in both stereo modes and back through the GPU decoder."""
+    import hashlib
+    shapes = [(20, 6 * 44100, 2, 16, 44100, synth.options(4096, 12)), (6, 10 * 44100 // 6, 1, 16, 44100, synth.options(4096, 12)),
+              (4, 48000, 8, 24, 192000, synth.options(16384, 32, force_lpc_order=32, max_partition_order=8, force_partition_order=8))]
+    files, oracle_checked = [], []
+    for first, (nf, ns, ch, bps, rate, o) in enumerate(shapes):
+        batch, _ = synth.make_batch(1000 * first, nf, ns, ch, bps, rate, o, nthreads=8)
+        oracle_checked.append(len(files))
+        files += [bytes(b) for b in batch]
+    pcms, res, infos = gpu_batch(decoder, files, out_fill=0x5A)
+    for i, (f, p, si, r) in enumerate(zip(files, pcms, infos, res)):
+        nfr = (si.total_samples + si.max_blocksize - 1) // si.max_blocksize
+        assert (r.frames, r.frames_ok, r.samples) == (nfr, nfr, si.total_samples), i
+        assert hashlib.md5(bytes(p)).hexdigest() == si.md5_signature, i
+    for i in oracle_checked:
+        want, ost = oracle_decode(infos[i], split_file(files[i])[1])
+        assert np.array_equal(pcms[i], want)
+    for mode in (flac_amd.STEREO_EXACT, flac_amd.STEREO_ESTIMATE):
+        sel = list(range(0, 20, 5)) + [20, 26]
+        packed = [bytes(pcms[i]) for i in sel]
+        shp = [(infos[i].total_samples, infos[i].sample_rate, infos[i].channels, infos[i].bits_per_sample) for i in sel]
+        from util import gpu_encode_group
+        enc, eres = gpu_encode_group(decoder, packed, shp, flac_amd.encode_options(blocksize=4096, max_lpc_order=12, max_partition_order=6,
+                                                                                    stereo_mode=mode, flags=flac_amd.ENC_MD5))
+        assert all(r.status == 0 for r in eres)
+        back, bres, binfos = gpu_batch(decoder, enc)
+        for b, want, si in zip(back, packed, binfos):
+            assert bytes(b) == want and hashlib.md5(want).hexdigest() == si.md5_signature
+
+
 def test_device_md5_matches_streaminfo(decoder, testdata):
     """flacgpu_md5_batch_device on the decoded PCM still in HBM: equals hashlib and the STREAMINFO
     signatures the reference's tests assert (flacmeta_test.go:37, :121), for lengths around the 64-byte
