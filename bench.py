@@ -188,7 +188,8 @@ def dominant_decode_kernel(classes, channels, bytes_ps):
         return "k_decode"
     width = {3: 0, 0: 1, 1: 2, 2: 3}        # arithmetic classes from narrowest (16-bit pairs) to widest (64-bit sums)
     b = max((i for i in range(8) if classes >> i & 1), key=lambda i: (width[i >> 1], i & 1))
-    layout = 1 if channels == 2 and bytes_ps == 2 else 2 if channels == 1 and bytes_ps == 2 and b >> 1 == 3 else 0
+    layout = (1 if channels == 2 and bytes_ps == 2 else 2 if channels == 1 and bytes_ps == 2 and b >> 1 == 3
+              else 3 if channels * bytes_ps >= 8 else 0)
     return f"k_decode<{32 if b & 1 else 12}, {b >> 1}, {layout}>"
 
 

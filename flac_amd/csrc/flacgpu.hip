@@ -382,6 +382,12 @@ static int decode_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
         } else if (r.C == 1 && r.B == 2) {
             FLACGPU_LAUNCH(12, 3, 2); FLACGPU_LAUNCH(32, 3, 2); FLACGPU_LAUNCH(12, 0, 0); FLACGPU_LAUNCH(32, 0, 0);
             FLACGPU_LAUNCH(12, 1, 0); FLACGPU_LAUNCH(32, 1, 0); FLACGPU_LAUNCH(12, 2, 0); FLACGPU_LAUNCH(32, 2, 0);
+        } else if (r.C * r.B >= 8 && r.B <= 2) {   // rows of at least a line: the sixteen-slot write-out
+            FLACGPU_LAUNCH(12, 3, 3); FLACGPU_LAUNCH(32, 3, 3); FLACGPU_LAUNCH(12, 0, 3); FLACGPU_LAUNCH(32, 0, 3);
+            FLACGPU_LAUNCH(12, 1, 3); FLACGPU_LAUNCH(32, 1, 3); FLACGPU_LAUNCH(12, 2, 3); FLACGPU_LAUNCH(32, 2, 3);
+        } else if (r.C * r.B >= 8) {
+            FLACGPU_LAUNCH(12, 0, 3); FLACGPU_LAUNCH(32, 0, 3); FLACGPU_LAUNCH(12, 1, 3); FLACGPU_LAUNCH(32, 1, 3);
+            FLACGPU_LAUNCH(12, 2, 3); FLACGPU_LAUNCH(32, 2, 3); FLACGPU_LAUNCH(12, 3, 3); FLACGPU_LAUNCH(32, 3, 3);
         } else if (r.B <= 2) {
             FLACGPU_LAUNCH(12, 3, 0); FLACGPU_LAUNCH(32, 3, 0); FLACGPU_LAUNCH(12, 0, 0); FLACGPU_LAUNCH(32, 0, 0);
             FLACGPU_LAUNCH(12, 1, 0); FLACGPU_LAUNCH(32, 1, 0); FLACGPU_LAUNCH(12, 2, 0); FLACGPU_LAUNCH(32, 2, 0);

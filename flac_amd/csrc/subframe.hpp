@@ -572,8 +572,10 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 //            fit 16 bits, which a 17-bit side channel almost always does; a lane that meets one that does
 //            not is rolled back like a lane with an over-long Rice code, and the generic body (24-bit
 //            multiplies) decodes until its history fits again.
-// LAYOUT: 0 = any channel count and sample size (the general write-out); 1 = C == 2 and B == 2 (STEREO16), the
-//         write-out specialised for it; 2 = C == 1 and B == 2 in the 16-bit pair class (MONO16).
+// LAYOUT: 0 = any channel count and sample size whose rows are shorter than a line (C * B < 8: the general
+//         write-out in four-slot items); 1 = C == 2 and B == 2 (STEREO16), the write-out specialised for it;
+//         2 = C == 1 and B == 2 in the 16-bit pair class (MONO16); 3 = C * B >= 8 (WIDE: the general write-out in
+//         sixteen-slot items, tile rows 65 words apart).
 // Lanes stage their samples as coded; stereo decorrelation and packing to the output's sample size happen
 // in the write-out, once per output word.
 //
@@ -593,7 +595,11 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     // seconds of wave time apart, cost the memory system a quarter of the kernel's time).  The unrolled body of
     // that class only keeps samples that fit 16 bits; the few that do not (generic body, 17-bit side channels)
     // are marked in `widemask`, one bit per tile column, and send the write-out down its slow path.
-    constexpr bool STEREO16 = LAYOUT == 1, MONO16 = LAYOUT == 2;
+    constexpr bool STEREO16 = LAYOUT == 1, MONO16 = LAYOUT == 2, WIDE = LAYOUT == 3;
+    // words per sample column of the raw tile.  WIDE: a lane of the write-out reads channel j of column g (+ 8) of
+    // frame f, word 65 * column + C * f + j; with C = 8 the 32 lanes of a half wave (f = 0..3, g = 0..7) then
+    // fall into 32 different banks (with 66 words they shared 8)
+    constexpr uint32_t RS = WIDE ? 65u : kRawStride;
     static_assert(!MONO16 || ARITH == 3, "the mono layout stages packed 16-bit pairs, which only the 16-bit pair class makes");
     constexpr bool TILE16 = (STEREO16 && ARITH == 3) || MONO16;
     constexpr uint32_t kT = TILE16 ? 2 * kTile : kTile;
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     // Rows shorter than a 128-byte line (C * B < 8: mono, 8-bit and 24-bit stereo ...) keep the finer mapping
     // instead: an item is four slots (B dwords, one store), 4C items per frame, item = 64 * it + lane, it = 0 .. 3,
     // so that one store instruction covers whole rows of consecutive frames rather than a sliver of every row.
-    const bool wide_items = C * B >= 8;
+    constexpr bool wide_items = WIDE;
     uint32_t q_src[16] = {};      // wide: the item's sixteen slots; else [it * 4 + j]
     uint64_t q_dst[4] = {};       // wide: [0] only
     uint32_t q_meta[4] = {};
@@ -745,14 +751,15 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             uint32_t col = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const uint32_t slot = 16 * g + j;
+                // two runs of eight slots, 8 * C slots apart (with eight channels: sample columns g and g + 8)
+                const uint32_t slot = 8 * (g + (j >= 8 ? C : 0u)) + (uint32_t)(j & 7);
                 col = (slot * inv_c) >> 16;
-                q_src[j] = tile_lds + (ok ? (col * kRawStride + f * C + (slot - col * C)) * 4 : 0u);
+                q_src[j] = tile_lds + (ok ? (col * RS + f * C + (slot - col * C)) * 4 : 0u);
             }
             const uint32_t fc = ok ? f : 0u;
             const uint64_t dst_f = frame_dst(fc);
             const uint32_t meta = frame_meta(fc);
-            q_dst[0] = ok ? dst_f + g * 16 * B : 0;
+            q_dst[0] = ok ? dst_f + g * 8 * B : 0;
             q_meta[0] = ok ? (meta & 0xFFFFFu) | (col << 20) | (((meta >> 20) & 15u) << 24) : 0u;
         } else {
 #pragma unroll
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t slot = 4 * g + j;
                     col = (slot * inv_c) >> 16;
-                    q_src[it * 4 + j] = tile_lds + (ok ? (col * kRawStride + f * C + (slot - col * C)) * 4 : 0u);
+                    q_src[it * 4 + j] = tile_lds + (ok ? (col * RS + f * C + (slot - col * C)) * 4 : 0u);
                 }
                 const uint32_t fc = ok ? f : 0u;
                 const uint64_t dst_f = frame_dst(fc);
@@ -876,7 +883,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 tile_half[((col >> 1) * kPairStride + lane) * 2 + (~col & 1u)] = (uint16_t)x;
             }
         } else {
-            if (ALWAYS || live) tile_raw[col * kRawStride + lane] = x;
+            if (ALWAYS || live) tile_raw[col * RS + lane] = x;
         }
     };
     // Sum of coef[j] * x[j] over the NT taps in the wave's arithmetic class, shifted.  The taps are
@@ -1115,10 +1122,13 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                         if (q)
 #endif
                         {
+                            // the item's two runs of eight slots lie 8 * C slots apart
+                            uint8_t *const q2 = q + 8 * CB;
                             if (B == 4) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k)
-                                    reinterpret_cast<Dwords4 *>(q)[k] = Dwords4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+                                reinterpret_cast<Dwords4 *>(q)[0] = Dwords4{v[0], v[1], v[2], v[3]};
+                                reinterpret_cast<Dwords4 *>(q)[1] = Dwords4{v[4], v[5], v[6], v[7]};
+                                reinterpret_cast<Dwords4 *>(q2)[0] = Dwords4{v[8], v[9], v[10], v[11]};
+                                reinterpret_cast<Dwords4 *>(q2)[1] = Dwords4{v[12], v[13], v[14], v[15]};
                             } else if (B == 3) {
                                 uint32_t d[12];
 #pragma unroll
@@ -1126,21 +1136,23 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                                     const uint32_t w[4] = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
                                     pack(w, d[3 * k], d[3 * k + 1], d[3 * k + 2]);
                                 }
-#pragma unroll
-                                for (int k = 0; k < 3; ++k)
-                                    reinterpret_cast<Dwords4 *>(q)[k] = Dwords4{d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]};
+                                *reinterpret_cast<Dwords4 *>(q) = Dwords4{d[0], d[1], d[2], d[3]};
+                                *reinterpret_cast<Dwords2 *>(q + 16) = Dwords2{d[4], d[5]};
+                                *reinterpret_cast<Dwords4 *>(q2) = Dwords4{d[6], d[7], d[8], d[9]};
+                                *reinterpret_cast<Dwords2 *>(q2 + 16) = Dwords2{d[10], d[11]};
                             } else if (B == 2) {
                                 uint32_t d[8];
 #pragma unroll
                                 for (int k = 0; k < 8; ++k) d[k] = (v[2 * k] & 0xFFFFu) | (v[2 * k + 1] << 16);
-                                reinterpret_cast<Dwords4 *>(q)[0] = Dwords4{d[0], d[1], d[2], d[3]};
-                                reinterpret_cast<Dwords4 *>(q)[1] = Dwords4{d[4], d[5], d[6], d[7]};
+                                *reinterpret_cast<Dwords4 *>(q) = Dwords4{d[0], d[1], d[2], d[3]};
+                                *reinterpret_cast<Dwords4 *>(q2) = Dwords4{d[4], d[5], d[6], d[7]};
                             } else {
                                 uint32_t d[4];
 #pragma unroll
                                 for (int k = 0; k < 4; ++k)
                                     d[k] = (v[4 * k] & 0xFFu) | ((v[4 * k + 1] & 0xFFu) << 8) | ((v[4 * k + 2] & 0xFFu) << 16) | (v[4 * k + 3] << 24);
-                                *reinterpret_cast<Dwords4 *>(q) = Dwords4{d[0], d[1], d[2], d[3]};
+                                *reinterpret_cast<Dwords2 *>(q) = Dwords2{d[0], d[1]};
+                                *reinterpret_cast<Dwords2 *>(q2) = Dwords2{d[2], d[3]};
                             }
                         }
                     }
@@ -1181,12 +1193,15 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 const uint32_t fbs_f = meta & 0xFFFFFu;
                 if (t0 >= fbs_f) continue;
                 const uint32_t ncols = min(kTile, fbs_f - t0);   // sample columns of this tile that exist in the frame
-                if (dwords && (((wide_items ? 16 * (g >> 2) + 15 : 4 * g + 3) * inv_c) >> 16) < ncols) continue;   // its item was written above
+                // written above?  WIDE: these four slots are half of run g >> 1 of the frame, which belongs to the item
+                // of channel lane (g >> 1) % C, whose last slot is the end of its second run
+                const uint32_t last_slot = wide_items ? 8 * (((g >> 1) % C) + C) + 7 : 4 * g + 3;
+                if (dwords && ((last_slot * inv_c) >> 16) < ncols) continue;
                 uint32_t v[4], nvalid = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t slot = 4 * g + j, col = (slot * inv_c) >> 16, chn = slot - col * C;
-                    v[j] = tile_raw[col * kRawStride + f * C + chn];
+                    v[j] = tile_raw[col * RS + f * C + chn];
                     nvalid += col < ncols ? 1u : 0u;
                 }
                 if (C == 2) {   // slots are (a, b) of two consecutive samples
@@ -1370,7 +1385,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 if (!redo) {
 #pragma unroll
                     for (int P = 0; P < (int)kT; ++P)
-                        tile_raw[(uint32_t)P * kRawStride + lane] = (uint32_t)ring[(first + P) % U] << h.wasted;
+                        tile_raw[(uint32_t)P * RS + lane] = (uint32_t)ring[(first + P) % U] << h.wasted;
                 }
             };
             if (U > (int)kT) restage(0);

@@ -1,5 +1,5 @@
 set -e
-run() { name=$1; shift; timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-files 0 --encode-steps 0 "$@" > gpurun_out/shape_$name.json 2> gpurun_out/shape_$name.log; python -c "
+run() { name=$1; shift; timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-files 0 --host-files 0 --encode-steps 0 "$@" > gpurun_out/shape_$name.json 2> gpurun_out/shape_$name.log; python -c "
 import json,sys
 d=json.load(open('gpurun_out/shape_$name.json')); print('$name', '%.3g'%d['value'], {k:round(v,2) for k,v in d['kernel_ms'].items()}, round(d['roofline']['frac'],3))"; }
 run mono16 --files 2000 --unique 64 --channels 1
