@@ -696,10 +696,12 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     uint32_t dc_rmask[NIT] = {};
     uint32_t dc_half2[NIT] = {}, dc_lmul2[NIT] = {}, dc_rmul2[NIT] = {};   // the same in both 16-bit halves of a word
     bool row16[NIT] = {};   // the frame's rows of four words start on 16-byte boundaries
-    // Other layouts: a frame's 16 samples x C channels are 16C sample slots in output order.  A lane's work
-    // item is sixteen consecutive slots of one frame = 16 B output bytes = B stores of 16 bytes: a frame has C
-    // items, the wave F * C <= 64 of them, lane = f * C + g.  (Four stores of B dwords per lane, four slots
-    // each, cost the 24-bit 8-channel shape a sixth of its time: the wave's store instructions queue.)
+    // Other layouts: a frame's 16 samples x C channels are 16C sample slots in output order.  WIDE: a lane's
+    // work item is sixteen slots of its own frame, two runs of eight consecutive slots 8C slots apart = 16 B
+    // output bytes: a frame has C items, the wave F * C <= 64 of them, lane = f * C + g.  (Four stores of B
+    // dwords per lane, four slots each, cost the 24-bit 8-channel shape a sixth of its time: the wave's store
+    // instructions queue; sixteen consecutive slots per lane put the LDS reads of a half wave into a quarter
+    // of the banks.)
     // Divisions by C and 4C are multiplications by rounded-up 16-bit reciprocals (exact while dividend x
     // divisor < 2^16; dividends here are below 256, divisors at most 32).
     const uint32_t inv_c = 65536u / C + 1, inv_4c = 65536u / (4 * C) + 1;
