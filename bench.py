@@ -299,7 +299,12 @@ def main(argv=None):
 
     # ---- corpus: UNIQUE files synthesised + encoded on the host ------------------------------
     threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-    enc_threads = max(1, threads // max(1, min(world, 8))) if world > 1 else threads
+    # every rank makes its own corpus: a node's CPUs are shared by its ranks (a GPU's share is 16 or more of them)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    enc_threads = max(1, min(threads, usable // world)) if world > 1 else threads
     t0 = time.time()
     okw = dict(max_partition_order=args.partition_order)
     if args.force_lpc_order:
