@@ -28,6 +28,10 @@ using namespace flacgpu;
 #include "handle.hpp"
 #include "host_stage.hpp"
 
+#include <dlfcn.h>
+
+#include <cstdlib>
+
 namespace {
 
 CandArrays cand_arrays(flacgpu_handle *h)
@@ -60,9 +64,38 @@ int reserve_candidates(flacgpu_handle *h, uint32_t n)
     return FLACGPU_OK;
 }
 
+// rocTX ranges around the host side of every stage (what rocprofv3 --marker-trace shows), only when the
+// environment asks for them: FLACGPU_ROCTX=1 loads the rocTX library at the first call; without it, or
+// without the library, nothing happens.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = std::getenv("FLACGPU_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        // rocprofv3 listens to the rocprofiler-sdk flavour of the library, older tools to roctracer's
+        void *lib = nullptr;
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+            if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop) push = nullptr;
+    }
+};
+
+// End of stage `which` on stream s: its timing event, and the range of the stage that follows.
 void mark(flacgpu_handle *h, int which, hipStream_t s)
 {
     if (h->flags & FLACGPU_FLAG_TIMING) (void)hipEventRecord(h->ev[which], s);
+    static const Roctx roctx;
+    if (roctx.push) {
+        static const char *const next_stage[EV_COUNT] = {"flacgpu:scan", "flacgpu:compact", "flacgpu:crc16", "flacgpu:resolve",
+                                                         "flacgpu:skim", "flacgpu:decode", "flacgpu:results", nullptr};
+        if (which != EV_START) (void)roctx.pop();
+        if (next_stage[which]) (void)roctx.push(next_stage[which]);
+    }
 }
 
 // Validates the batch description and builds the device stream table.
