@@ -55,6 +55,9 @@ constexpr uint32_t kFetchBelow = kRingWords >= 32 ? 17 : kRingWords - kUnitWords
 #define FLACGPU_SKIM_PAIR_K 9
 #endif
 constexpr uint32_t kSkimPairK = FLACGPU_SKIM_PAIR_K;
+#ifndef FLACGPU_SKIM_WIDE
+#define FLACGPU_SKIM_WIDE 1   // 0: one code per 32-bit window where two do not fit one (the earlier loop)
+#endif
 // Compile-time loops: the body gets its index as a std::integral_constant (the unrolled loops index register arrays).
 template <int N, int I = 0, class F>
 __device__ inline void static_for_each(F &&f)
@@ -173,6 +176,16 @@ struct BitReader {
         return uint2{q[0], q[64]};
     }
     static __device__ inline uint32_t window_neg(uint2 words, uint32_t Q) { return __builtin_amdgcn_alignbit(words.x, words.y, Q); }
+    // The 64 bits at P, for a ring with two mirror slots (see ring_round<true>): high and low word.
+    __device__ inline uint2 peek64_ring_neg(uint32_t Q) const
+    {
+        typedef __attribute__((address_space(3))) const uint32_t lds_word;
+        const uint32_t top = (uint32_t)(uintptr_t)(lds_word *)(ring + (kRingWords - 1) * 64);
+        const uint32_t idx = __builtin_amdgcn_ubfe(Q, 5, kRingLog2);
+        lds_word *q = (lds_word *)(uintptr_t)mad_i24((int32_t)idx, -256, (int32_t)top);
+        const uint32_t a = q[0], b = q[64], c = q[128];
+        return uint2{__builtin_amdgcn_alignbit(a, b, Q), __builtin_amdgcn_alignbit(b, c, Q)};
+    }
     __device__ inline bool starved() const { return (P >> 5) + 1 >= fill; }
     __device__ inline uint32_t peek() const
     {
@@ -216,6 +229,7 @@ struct RingFetch {
 // decode loops never wait for memory.  After repositioning, three rounds in a row restore the margin.
 // Each lane loads for itself: 64 lanes touch 64 different lines either way, and the two 16-byte
 // loads of a lane fall into one 32-byte sector.
+template <bool MIRROR2 = false>   // MIRROR2: the ring has a second extra slot that repeats slot 1 (three-word windows)
 __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active)
 {
     // ---- commit
@@ -231,7 +245,10 @@ __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active)
         dst[5 * 64] = __builtin_bswap32(rf.v[1].y);
         dst[6 * 64] = __builtin_bswap32(rf.v[1].z);
         dst[7 * 64] = __builtin_bswap32(rf.v[1].w);
-        if (slot == 0) br.ring[kRingWords * 64] = w0;
+        if (slot == 0) {
+            br.ring[kRingWords * 64] = w0;
+            if (MIRROR2) br.ring[(kRingWords + 1) * 64] = __builtin_bswap32(rf.v[0].y);
+        }
         br.fill += kUnitWords;
     }
     // ---- issue
@@ -368,10 +385,11 @@ __device__ inline uint32_t wave_max_u32(uint32_t v)
 __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, uint64_t in_vecs, CandArrays c,
                                               uint32_t r_begin, uint32_t r_end, uint32_t C, const uint4 *spare)
 {
-    __shared__ __align__(16) uint32_t s_ring[4 * kRingSlots * 64];
+    constexpr uint32_t kSlots = kRingSlots + 1;   // a second mirror slot: the wide-window loop reads three consecutive words
+    __shared__ __align__(16) uint32_t s_ring[4 * kSlots * 64];
     constexpr uint32_t G = 16;
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t *wave_ring = s_ring + (threadIdx.x >> 6) * (kRingSlots * 64);
+    uint32_t *wave_ring = s_ring + (threadIdx.x >> 6) * (kSlots * 64);
     const uint32_t r = r_begin + blockIdx.x * blockDim.x + threadIdx.x;
     bool active = r < r_end;
     if (active) active = c.status[r] == kFrameOK;
@@ -448,11 +466,11 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
             if (part_rem == 0) rice = false;   // no partition left
         };
 
-        ring_round(br, rf, rice);
-        ring_round(br, rf, rice);
+        ring_round<true>(br, rf, rice);
+        ring_round<true>(br, rf, rice);
         const uint32_t bs_max = wave_max_u32(rice ? bs : 0);
         for (uint32_t n0 = 0; n0 < bs_max; n0 += G) {
-            ring_round(br, rf, rice);
+            ring_round<true>(br, rf, rice);
             if (rice && n0 < bs && br.pos() > limit) kill(kFrameTruncated);
             if (rice && n0 < bs && part_rem == 0 && n0 >= order) open_partition();
             const bool on = rice && n0 < bs;
@@ -481,17 +499,36 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
                         Q -= tot;
                     }
                 } else {
+#if FLACGPU_SKIM_WIDE
+                    // two codes per 64-bit window: either code may be up to 32 bits long.  The OR of the lengths
+                    // exceeds 32 when one of them does (and, harmlessly, when one is exactly 32 beside another).
+#pragma unroll
+                    for (int P = 0; P < (int)G / 2; ++P) {
+                        if (2 * P == (int)kRoundSteps) {
+                            br.P = 0u - Q;
+                            starved = starved || br.starved();
+                            ring_round<true>(br, rf, reads);
+                        }
+                        const uint2 w = br.peek64_ring_neg(Q);
+                        const uint32_t n1 = __clz(w.x) + 1 + k;
+                        const uint32_t w2 = __builtin_amdgcn_alignbit(w.x, w.y, 32u - n1);   // the window n1 bits on (n1 <= 32, else the lane is redone)
+                        const uint32_t n2 = __clz(w2) + 1 + k;
+                        longest |= n1 | n2;
+                        Q -= n1 + n2;
+                    }
+#else
 #pragma unroll
                     for (int P = 0; P < (int)G; ++P) {
                         if (P == (int)kRoundSteps) {
                             br.P = 0u - Q;
                             starved = starved || br.starved();
-                            ring_round(br, rf, reads);
+                            ring_round<true>(br, rf, reads);
                         }
                         const uint32_t nb = __clz(br.peek_ring_neg(Q)) + 1 + k;
                         longest = max(longest, nb);
                         Q -= nb;
                     }
+#endif
                 }
                 br.P = 0u - Q;
                 starved = starved || br.starved();
@@ -505,7 +542,7 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
             }
             if (run_generic) {
                 for (uint32_t n = n0; n < n0 + G; ++n) {
-                    if (n - n0 == kRoundSteps) ring_round(br, rf, rice);
+                    if (n - n0 == kRoundSteps) ring_round<true>(br, rf, rice);
                     if (redo && rice && n >= order && n < bs) {
                         if (part_rem == 0) open_partition();
                         if (rice) {
