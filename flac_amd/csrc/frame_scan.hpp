@@ -448,12 +448,11 @@ __device__ inline void crc16_pow_table(uint16_t *pow2)
 }
 
 // Lookup tables of k_crc16_spans, built once per handle (uint16 entries):
-//   skip[h][v]   (2 x 256)   multiplication of a 16-bit remainder by x^(8 * 1024), split by byte
 //   lanew[l]     (64)        x^(8 * 16 * (63 - l))
 //   remw[r]      (16)        x^(8 * r)
 //   pow2[k]      (32)        x^(8 * 2^k), for gf_xpow8
 //   inv[r]       (16)        x^(-8 * r): x has order 32767 modulo 0x18005 = (x + 1)(x^15 + x + 1)
-constexpr int kCrcSkip = 0, kCrcLane = kCrcSkip + 512, kCrcRem = kCrcLane + 64,
+constexpr int kCrcLane = 0, kCrcRem = kCrcLane + 64,
               kCrcPow2 = kCrcRem + 16, kCrcInv = kCrcPow2 + 32, kCrcTableEntries = kCrcInv + 16;
 
 __global__ void k_crc16_build_tables(uint16_t *t)
@@ -463,10 +462,7 @@ __global__ void k_crc16_build_tables(uint16_t *t)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries; i += blockDim.x) {
         uint32_t v;
-        if (i < (uint32_t)kCrcLane) {
-            const uint32_t hsel = (i - kCrcSkip) >> 8, byte = i & 255;
-            v = gf_mulmod(hsel ? byte << 8 : byte, gf_xpow8(1024, s_pow2));
-        } else if (i < (uint32_t)kCrcRem) {
+        if (i < (uint32_t)kCrcRem) {
             v = gf_xpow8(16 * (63 - (i - kCrcLane)), s_pow2);
         } else if (i < (uint32_t)kCrcPow2) {
             v = gf_xpow8(i - kCrcRem, s_pow2);
@@ -505,13 +501,78 @@ __device__ inline uint32_t crc16_piece(const uint4 v)
     return t ^ (0x8003u & (0u - flip));
 }
 
+// The same for a message of four words given most significant first.
+__device__ inline uint32_t crc16_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    const uint32_t parity = __popc(w0) + __popc(w1) + __popc(w2) + __popc(w3);
+    const uint32_t a = crc16_fold15(w0), b = crc16_fold15(w1), c = crc16_fold15(w2), d = crc16_fold15(w3);
+    uint32_t t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d;
+    t = crc16_fold15(t);
+    t = (t << 2) ^ (t << 1);
+    t = crc16_fold15(t);
+    const uint32_t flip = (parity + __popc(t)) & 1u;
+    return t ^ (0x8003u & (0u - flip));
+}
+
+// Wide accumulators.  A lane of a wave that steps over a message 1 KiB at a time sees pieces that are 8192 bit
+// positions apart, and modulo P = x^16 + x^15 + x^2 + 1 (x has order 32767)
+//     x^32768 = x,     x^8192 = x^8 + x^4 + x,     x^128 = x^8 + x^2 + x
+// (relations with an even number of terms hold modulo x + 1 as well as modulo x^15 + x + 1, so modulo P).  Pieces
+// four steps apart therefore differ by a factor x: a lane keeps four accumulators, one per step index modulo 4,
+// and adds a piece to its accumulator as  A = A * x + piece  on the unreduced 128-bit value (a one-bit shift over
+// five words and four XORs) instead of reducing every piece to 16 bits.  A fifth word takes the bits shifted out:
+// 32 steps per accumulator, then crc16_acc_fold brings it back to 128 bits (x^128 above).  The four accumulators
+// are joined by Horner's rule with x^8192 and reduced once per message (crc16_acc_flush).
+struct CrcAcc { uint32_t w[5]; };   // w[0] least significant
+__device__ inline void crc16_acc_clear(CrcAcc &A) { A.w[0] = A.w[1] = A.w[2] = A.w[3] = A.w[4] = 0; }
+__device__ inline void crc16_acc_step(CrcAcc &A, const uint4 v)   // v: 16 message bytes in memory order
+{
+    A.w[4] = __builtin_amdgcn_alignbit(A.w[4], A.w[3], 31);
+    A.w[3] = __builtin_amdgcn_alignbit(A.w[3], A.w[2], 31) ^ __builtin_bswap32(v.x);
+    A.w[2] = __builtin_amdgcn_alignbit(A.w[2], A.w[1], 31) ^ __builtin_bswap32(v.y);
+    A.w[1] = __builtin_amdgcn_alignbit(A.w[1], A.w[0], 31) ^ __builtin_bswap32(v.z);
+    A.w[0] = (A.w[0] << 1) ^ __builtin_bswap32(v.w);
+}
+__device__ inline void crc16_acc_add(CrcAcc &A, const uint4 v)    // a piece of the accumulator's newest step, no shift
+{
+    A.w[3] ^= __builtin_bswap32(v.x); A.w[2] ^= __builtin_bswap32(v.y);
+    A.w[1] ^= __builtin_bswap32(v.z); A.w[0] ^= __builtin_bswap32(v.w);
+}
+// t * x^128 folded onto (lo, hi) = the words 128 and 96 bit positions below t
+__device__ inline void crc16_fold128(uint32_t t, uint32_t &lo, uint32_t &hi)
+{
+    lo ^= (t << 8) ^ (t << 2) ^ (t << 1);
+    hi ^= (t >> 24) ^ (t >> 30) ^ (t >> 31);
+}
+__device__ inline void crc16_acc_fold(CrcAcc &A)
+{
+    crc16_fold128(A.w[4], A.w[0], A.w[1]);
+    A.w[4] = 0;
+}
+// CRC-16 of a lane's pieces: n0 holds the newest step (weight 1), n1 the step before it (x^8192), n2, n3.
+__device__ inline uint32_t crc16_acc_flush(const CrcAcc &n0, const CrcAcc &n1, const CrcAcc &n2, const CrcAcc &n3)
+{
+    uint32_t h[6] = {n3.w[0], n3.w[1], n3.w[2], n3.w[3], n3.w[4], 0u};
+    auto horner = [&](const CrcAcc &n) {   // h = h * (x^8 + x^4 + x) + n
+#pragma unroll
+        for (int i = 5; i >= 1; --i)
+            h[i] = __builtin_amdgcn_alignbit(h[i], h[i - 1], 24) ^ __builtin_amdgcn_alignbit(h[i], h[i - 1], 28) ^
+                   __builtin_amdgcn_alignbit(h[i], h[i - 1], 31) ^ (i < 5 ? n.w[i] : 0u);
+        h[0] = (h[0] << 8) ^ (h[0] << 4) ^ (h[0] << 1) ^ n.w[0];
+    };
+    horner(n2); horner(n1); horner(n0);
+    crc16_fold128(h[5], h[1], h[2]);
+    crc16_fold128(h[4], h[0], h[1]);
+    return crc16_words(h[3], h[2], h[1], h[0]);
+}
+
 // CRC-16 of every candidate span [goff[r], goff[r] + seglen[r]).  One wave per span at a time (waves
 // stride over the spans).  The span is cut into 16-byte pieces on 16-byte boundaries; the bytes of the
 // first piece before the span and of the last piece after it are taken as zeros (leading zeros do not
 // change a CRC that starts from zero; trailing zeros multiply it by a known power of x, divided out at
-// the end).  Lanes load consecutive pieces (1 KiB per wave per step), reduce each to its remainder
-// (crc16_piece), and carry it over the 1 KiB stride by a table multiplication; at the end the 64
-// partial remainders are weighted by lane and XOR-ed.  The next step's piece (or the first piece of the
+// the end).  Lanes load consecutive pieces (1 KiB per wave per step) and add each to one of four wide
+// accumulators (crc16_acc_step); at the end of the span a lane reduces its accumulators to one remainder,
+// and the 64 remainders are weighted by lane and XOR-ed.  The next step's piece (or the first piece of the
 // wave's next span) is loaded before the current one is processed.
 __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__ in, CandArrays c, uint32_t n_cand,
                                                      const uint16_t *__restrict__ tables)
@@ -520,7 +581,6 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries / 2; i += blockDim.x)
         reinterpret_cast<uint32_t *>(s_t)[i] = reinterpret_cast<const uint32_t *>(tables)[i];
     __syncthreads();
-    const uint16_t *skip = s_t + kCrcSkip;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t lanew = s_t[kCrcLane + lane];
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
@@ -571,7 +631,8 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
         const uint32_t r_next = r + waves;
         Span g_next = g;
         if (r_next < n_cand) g_next = geometry(c.goff[r_next], c.seglen[r_next]);
-        uint32_t acc = 0;
+        CrcAcc a0, a1, a2, a3;   // by the step's distance from the span's last step, modulo 4
+        crc16_acc_clear(a0); crc16_acc_clear(a1); crc16_acc_clear(a2); crc16_acc_clear(a3);
         const uint32_t steps = uniform32(g.steps);
         const bool more = uniform32(r_next < n_cand ? 1u : 0u) != 0;
         for (uint32_t t = 0; t < steps; ++t) {
@@ -581,10 +642,16 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
             const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)g.pad;
             if (t == 0 && g.lead && j == 0) cur = keep_bytes(cur, g.lead, 16);
             if (t + 1 == steps && g.trail && j == (int32_t)g.npieces - 1) cur = keep_bytes(cur, 0, 16 - g.trail);
-            const uint32_t pc = crc16_piece(cur);
-            acc = skip[acc & 0xFF] ^ skip[256 + (acc >> 8)] ^ pc;
+            switch ((steps - 1 - t) & 3u) {
+            case 0: crc16_acc_step(a0, cur); break;
+            case 1: crc16_acc_step(a1, cur); break;
+            case 2: crc16_acc_step(a2, cur); break;
+            default: crc16_acc_step(a3, cur); break;
+            }
+            if ((t & 127u) == 127u) { crc16_acc_fold(a0); crc16_acc_fold(a1); crc16_acc_fold(a2); crc16_acc_fold(a3); }
             cur = nxt;
         }
+        uint32_t acc = crc16_acc_flush(a0, a1, a2, a3);
         acc = gf_mulmod(acc, lanew);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) acc ^= __shfl_xor(acc, d);

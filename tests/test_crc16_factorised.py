@@ -36,3 +36,69 @@ def test_piece_remainder_equals_crc16():
     cases += [bytes(rng.integers(0, 256, size=16).astype(np.uint8)) for _ in range(3000)]
     for m in cases:
         assert piece_remainder(m) == oracle.crc16(m), m.hex()
+
+
+# ---- wide accumulators (crc16_acc_step / crc16_acc_fold / crc16_acc_flush of frame_scan.hpp), word by word ----
+
+_M32 = 0xFFFFFFFF
+
+
+def _alignbit(hi, lo, s):          # v_alignbit_b32
+    return (((hi << 32) | lo) >> (s & 31)) & _M32
+
+
+def _acc_step(A, piece):           # A[0] least significant; piece: 16 bytes in memory order
+    W = [int.from_bytes(piece[4 * i: 4 * i + 4], "big") for i in range(4)]
+    A[4] = _alignbit(A[4], A[3], 31)
+    A[3] = _alignbit(A[3], A[2], 31) ^ W[0]
+    A[2] = _alignbit(A[2], A[1], 31) ^ W[1]
+    A[1] = _alignbit(A[1], A[0], 31) ^ W[2]
+    A[0] = ((A[0] << 1) & _M32) ^ W[3]
+
+
+def _fold128(t, lo, hi):           # x^128 = x^8 + x^2 + x
+    return lo ^ (((t << 8) ^ (t << 2) ^ (t << 1)) & _M32), hi ^ (t >> 24) ^ (t >> 30) ^ (t >> 31)
+
+
+def _acc_fold(A):
+    A[0], A[1] = _fold128(A[4], A[0], A[1])
+    A[4] = 0
+
+
+def _acc_flush(n0, n1, n2, n3):    # newest step first; Horner with x^8192 = x^8 + x^4 + x
+    h = list(n3) + [0]
+    for n in (n2, n1, n0):
+        new = [0] * 6
+        for i in range(5, 0, -1):
+            new[i] = (_alignbit(h[i], h[i - 1], 24) ^ _alignbit(h[i], h[i - 1], 28) ^ _alignbit(h[i], h[i - 1], 31)
+                      ^ (n[i] if i < 5 else 0))
+        new[0] = (((h[0] << 8) ^ (h[0] << 4) ^ (h[0] << 1)) & _M32) ^ n[0]
+        h = new
+    h[1], h[2] = _fold128(h[5], h[1], h[2])
+    h[0], h[1] = _fold128(h[4], h[0], h[1])
+    return piece_remainder(b"".join(w.to_bytes(4, "big") for w in (h[3], h[2], h[1], h[0])))
+
+
+def lane_remainder(pieces):
+    """What one lane of k_crc16_spans computes: the CRC-16 of its 16-byte pieces taken 1 KiB apart, the last one
+    ending the message."""
+    steps = len(pieces)
+    acc = [[0] * 5 for _ in range(4)]
+    for t, piece in enumerate(pieces):
+        _acc_step(acc[(steps - 1 - t) & 3], piece)
+        if (t & 127) == 127:
+            for a in acc:
+                _acc_fold(a)
+    return _acc_flush(*acc)
+
+
+def test_wide_accumulators_equal_crc16():
+    rng = np.random.default_rng(17)
+    for steps in list(range(1, 14)) + [127, 128, 129, 255, 256, 257, 700]:
+        for kind in ("random", "ones"):
+            if kind == "random":
+                pieces = [bytes(rng.integers(0, 256, size=16).astype(np.uint8)) for _ in range(steps)]
+            else:
+                pieces = [bytes([0xFF] * 16)] * steps
+            message = (b"".join(p + bytes(1008) for p in pieces[:-1])) + pieces[-1]
+            assert lane_remainder(pieces) == oracle.crc16(message), (steps, kind)
