@@ -130,7 +130,7 @@ class Timing(ctypes.Structure):
                 ("resolve_ms", ctypes.c_float), ("skim_ms", ctypes.c_float), ("decode_ms", ctypes.c_float),
                 ("results_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("candidates", ctypes.c_uint64),
                 ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64), ("decode_classes", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32)]
+                ("crc16_reread_spans", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -144,11 +144,12 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     if ((rc = reserve(h, h->group_sum, (size_t)n_groups * 4))) return rc;
     if ((rc = reserve(h, h->group_base, (size_t)n_groups * 4))) return rc;
     if ((rc = reserve(h, h->counter, 64))) return rc;
+    if ((rc = reserve(h, h->segrec, (size_t)n_tiles * 4 * kSegSlots * 4))) return rc;
 
     HIP_TRY(hipMemcpyAsync(h->streams.p, h->h_streams.data(), (size_t)n * sizeof(StreamDev), hipMemcpyHostToDevice, st));
     mark(h, EV_START, st);
     k_scan_tiles<<<n_tiles, 256, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (uint16_t *)h->mask.p,
-                                          (uint64_t *)h->bitmap.p, (uint32_t *)h->tile_count.p);
+                                          (uint64_t *)h->bitmap.p, (uint32_t *)h->tile_count.p, (uint32_t *)h->segrec.p);
     mark(h, EV_SCAN, st);
     k_tile_prefix_local<<<n_groups, 1024, 0, st>>>((const uint32_t *)h->tile_count.p, (uint32_t *)h->tile_base.p, n_tiles,
                                                    (uint32_t *)h->group_sum.p);
@@ -169,8 +170,14 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     k_stream_ranges<<<(n + 255) / 256, 256, 0, st>>>((StreamDev *)h->streams.p, n, c.goff, n_cand);
     mark(h, EV_COMPACT, st);
     if (n_cand) {
+        // span CRCs from the scan's cut records; the few spans the records cannot give (h->next as their list, which the
+        // resolve step overwrites afterwards) are read again
+        uint32_t *fb_count = (uint32_t *)h->counter.p + 1;
+        HIP_TRY(hipMemsetAsync(fb_count, 0, 4, st));
+        k_span_crc<<<(n_cand + 255) / 256, 256, 0, st>>>(c, n_cand, (const uint32_t *)h->segrec.p, (const uint16_t *)h->crc_tables.p,
+                                                         c.next, fb_count);
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_cand + 3) / 4, 256 * 8);
-        k_crc16_spans<<<blocks, 256, 0, st>>>(d_in, c, n_cand, (const uint16_t *)h->crc_tables.p);
+        k_crc16_spans<<<blocks, 256, 0, st>>>(d_in, c, n_cand, (const uint16_t *)h->crc_tables.p, c.next, fb_count);
     }
     mark(h, EV_CRC, st);
     if (n_cand) {
@@ -180,6 +187,8 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     }
     mark(h, EV_RESOLVE, st);
     HIP_TRY(hipMemcpyAsync(h->h_streams.data(), h->streams.p, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost, st));
+    h->n_reread = 0;
+    if (n_cand) HIP_TRY(hipMemcpyAsync(&h->n_reread, (uint32_t *)h->counter.p + 1, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
     return FLACGPU_OK;
@@ -210,7 +219,7 @@ void collect_timing(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes)
 {
     flacgpu_timing t;
     std::memset(&t, 0, sizeof t);
-    t.candidates = h->n_cand; t.in_bytes = in_bytes; t.out_bytes = out_bytes;
+    t.candidates = h->n_cand; t.in_bytes = in_bytes; t.out_bytes = out_bytes; t.crc16_reread_spans = h->n_reread;
     if (h->flags & FLACGPU_FLAG_TIMING) {
         auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, h->ev[a], h->ev[b]); return ms; };
         t.scan_ms = el(EV_START, EV_SCAN);
@@ -285,7 +294,7 @@ void flacgpu_destroy(flacgpu_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *all[] = {&h->streams, &h->results, &h->mask, &h->bitmap, &h->tile_count, &h->tile_base, &h->group_sum, &h->group_base,
-                     &h->counter, &h->crc_tables, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
+                     &h->counter, &h->crc_tables, &h->segrec, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
                      &h->seglen, &h->subpos, &h->next};
     for (DevBuf *b : all) release(*b);
     host_pipe_release(h);
@@ -477,6 +486,7 @@ constexpr size_t kNaSizes[] = {
     na_round(((kNaTiles + kPrefixGroup - 1) / kPrefixGroup) * 4),   // group_base
     na_round(64),                                     // counter
     na_round(kCrcTableEntries * 2),                   // crc_tables
+    na_round(kNaTiles * 4 * kSegSlots * 4),           // segrec
     na_round(kNaMaxCand * 8), na_round(kNaMaxCand * 8), na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 4),   // goff num info stream
     na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 2), na_round(kNaMaxCand * 4),   // len status segcrc seglen
     na_round(kNaMaxCand * 8 * 4), na_round(kNaMaxCand * 4),                                                  // subpos next
@@ -519,7 +529,7 @@ int noalloc_setup(NoAllocState &s, int device, hipStream_t st)
     if (e != hipSuccess || !ptr) return fail(h, FLACGPU_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
     s.ptr = ptr;
     DevBuf *bufs[] = {&h->streams, &h->results, &h->mask, &h->bitmap, &h->tile_count, &h->tile_base, &h->group_sum, &h->group_base,
-                      &h->counter, &h->crc_tables, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
+                      &h->counter, &h->crc_tables, &h->segrec, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
                       &h->seglen, &h->subpos, &h->next};
     static_assert(sizeof bufs / sizeof bufs[0] == sizeof kNaSizes / sizeof kNaSizes[0], "one size per buffer");
     size_t off = 0;
@@ -597,6 +607,7 @@ int flacgpu_decode_batch(flacgpu_handle *h, const uint8_t *const *bufs, const ui
         sum.scan_ms += t.scan_ms; sum.compact_ms += t.compact_ms; sum.crc16_ms += t.crc16_ms; sum.resolve_ms += t.resolve_ms;
         sum.skim_ms += t.skim_ms; sum.decode_ms += t.decode_ms; sum.results_ms += t.results_ms; sum.total_ms += t.total_ms;
         sum.candidates += t.candidates; sum.in_bytes += t.in_bytes; sum.out_bytes += t.out_bytes; sum.decode_classes |= t.decode_classes;
+        sum.crc16_reread_spans += t.crc16_reread_spans;
         return rc;
     };
     const int rc = run_staged(h, *host_pipe(h), items, h->own_stream, true, compute, [&](size_t i) { return out_caps[i]; });

@@ -126,6 +126,240 @@ __device__ inline uint32_t zero_bytes(uint32_t v)
 // 0x80-per-byte mask -> 4-bit mask
 __device__ inline uint32_t movemask4(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xF; }
 
+// ---------------------------------------------------------------- CRC-16 arithmetic ---
+
+// a * b in GF(2)[x] modulo x^16 + x^15 + x^2 + 1
+__device__ inline uint32_t gf_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+        r <<= 1;
+        if (r & 0x10000) r ^= 0x18005;
+        if ((b >> i) & 1) r ^= a;
+    }
+    return r & 0xFFFF;
+}
+
+// x^(8n) mod P, from a table of x^(8 * 2^k)
+__device__ inline uint32_t gf_xpow8(uint32_t n, const uint16_t *pow2)
+{
+    uint32_t r = 1;
+    for (int k = 0; n; ++k, n >>= 1)
+        if (n & 1) r = gf_mulmod(r, pow2[k]);
+    return r;
+}
+
+// CRC-16 of `len` bytes followed by `after` zero-weighted bytes: crc(msg) * x^(8*after)
+__device__ inline uint32_t crc16_shift(uint32_t crc, uint32_t after, const uint16_t *pow2)
+{
+    return after ? gf_mulmod(crc, gf_xpow8(after, pow2)) : crc;
+}
+
+// pow2[k] = x^(8 * 2^k) mod P, for gf_xpow8
+__device__ inline void crc16_pow_table(uint16_t *pow2)
+{
+    if (threadIdx.x == 0) {
+        uint32_t p = 0x100;  // x^8
+        for (int k = 0; k < 32; ++k) { pow2[k] = (uint16_t)p; p = gf_mulmod(p, p); }
+    }
+}
+
+// Lookup tables, built once per handle (uint16 entries):
+//   lanew[l]     (64)        x^(8 * 16 * (63 - l))
+//   remw[r]      (16)        x^(8 * r)
+//   pow2[k]      (32)        x^(8 * 2^k), for gf_xpow8
+//   inv[r]       (16)        x^(-8 * r): x has order 32767 modulo 0x18005 = (x + 1)(x^15 + x + 1)
+// and for k_span_crc, which joins the scan's cut records:
+//   invpad[n]    (1025)      x^(-8 * n), the zero bytes between a cut and the end of its 1 KiB step
+//   powlo[n]     (128)       x^(8 * n)
+//   powhi[n]     (129)       x^(8 * 128 * n): x^(8 * d) = powhi[d / 128] * powlo[d % 128] for d up to 16 KiB
+constexpr int kCrcLane = 0, kCrcRem = kCrcLane + 64, kCrcPow2 = kCrcRem + 16, kCrcInv = kCrcPow2 + 32,
+              kCrcCoreEntries = kCrcInv + 16, kCrcInvPad = kCrcCoreEntries, kCrcPowLo = kCrcInvPad + 1025,
+              kCrcPowHi = kCrcPowLo + 128, kCrcTableEntries = (kCrcPowHi + 129 + 1) & ~1;
+
+__global__ void k_crc16_build_tables(uint16_t *t)
+{
+    __shared__ uint16_t s_pow2[32];
+    crc16_pow_table(s_pow2);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries; i += blockDim.x) {
+        uint32_t v;
+        if (i < (uint32_t)kCrcRem) v = gf_xpow8(16 * (63 - (i - kCrcLane)), s_pow2);
+        else if (i < (uint32_t)kCrcPow2) v = gf_xpow8(i - kCrcRem, s_pow2);
+        else if (i < (uint32_t)kCrcInv) v = s_pow2[i - kCrcPow2];
+        else if (i < (uint32_t)kCrcInvPad) v = gf_xpow8((32767u - (i - kCrcInv)) % 32767u, s_pow2);
+        else if (i < (uint32_t)kCrcPowLo) v = gf_xpow8((32767u - (i - kCrcInvPad)) % 32767u, s_pow2);
+        else if (i < (uint32_t)kCrcPowHi) v = gf_xpow8(i - kCrcPowLo, s_pow2);
+        else v = gf_xpow8(128 * (i - kCrcPowHi), s_pow2);
+        t[i] = (uint16_t)v;
+    }
+}
+
+// CRC-16 of the 16 bytes of a vector taken as a message of its own (init 0), without tables: byte-table
+// lookups from 64 lanes collide in the LDS banks and made the kernel LDS-bound.
+// The polynomial factors: x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1).  Modulo x + 1 a polynomial is the
+// parity of its bits.  Modulo Q = x^15 + x + 1, x^15 = x + 1, so a high part h (bits 15 and up) folds down as
+// h + h*x; x^32 = x^4 + x^2, x^64 = x^8 + x^4, x^96 = x^12 + x^10 + x^8 + x^6 and x^16 = x^2 + x.  The
+// remainder r modulo Q and the parity p of the message give the CRC as r + c*Q with c = p + parity(r)
+// (Q has three terms, so adding it flips the parity).
+__device__ inline uint32_t crc16_fold15(uint32_t w)   // congruent to w modulo Q; below 2^18 for any w, below 2^15 for w < 2^19
+{
+    const uint32_t h = w >> 15;
+    return (w & 0x7FFFu) ^ h ^ (h << 1);
+}
+// Remainder modulo Q of a four-word message (most significant word first) times x^16; below 2^15.
+__device__ inline uint32_t crc16_words_q(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    const uint32_t a = crc16_fold15(w0), b = crc16_fold15(w1), c = crc16_fold15(w2), d = crc16_fold15(w3);
+    uint32_t t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d;   // < 2^30
+    t = crc16_fold15(t);             // < 2^17
+    t = (t << 2) ^ (t << 1);         // times x^16: the CRC is the remainder of message * x^16
+    return crc16_fold15(t);          // < 2^15: the remainder modulo Q
+}
+// The CRC from the remainder modulo Q and the message's parity (its low bit).
+__device__ inline uint32_t crc16_join(uint32_t q, uint32_t parity)
+{
+    const uint32_t flip = (parity + __popc(q)) & 1u;
+    return q ^ (0x8003u & (0u - flip));
+}
+__device__ inline uint32_t crc16_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    return crc16_join(crc16_words_q(w0, w1, w2, w3), __popc(w0) + __popc(w1) + __popc(w2) + __popc(w3));
+}
+__device__ inline uint32_t crc16_piece(const uint4 v)   // 16 message bytes in memory order
+{
+    return crc16_words(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+}
+
+// Wide accumulators.  A lane of a wave that steps over a message 1 KiB at a time sees pieces that are 8192 bit
+// positions apart, and modulo P = x^16 + x^15 + x^2 + 1 (x has order 32767)
+//     x^32768 = x,     x^8192 = x^8 + x^4 + x,     x^128 = x^8 + x^2 + x
+// (relations with an even number of terms hold modulo x + 1 as well as modulo x^15 + x + 1, so modulo P).  Pieces
+// four steps apart therefore differ by a factor x: a lane keeps four accumulators, one per step index modulo 4,
+// and adds a piece to its accumulator as  A = A * x + piece  on the unreduced 128-bit value (a one-bit shift over
+// five words and four XORs) instead of reducing every piece to 16 bits.  A fifth word takes the bits shifted out:
+// 32 steps per accumulator, then crc16_acc_fold brings it back to 128 bits (x^128 above).  The four accumulators
+// are joined by Horner's rule with x^8192 and reduced once per message (crc16_acc_flush).
+struct CrcAcc { uint32_t w[5]; };   // w[0] least significant
+__device__ inline void crc16_acc_clear(CrcAcc &A) { A.w[0] = A.w[1] = A.w[2] = A.w[3] = A.w[4] = 0; }
+__device__ inline void crc16_acc_step(CrcAcc &A, const uint4 v)   // v: 16 message bytes in memory order
+{
+    A.w[4] = __builtin_amdgcn_alignbit(A.w[4], A.w[3], 31);
+    A.w[3] = __builtin_amdgcn_alignbit(A.w[3], A.w[2], 31) ^ __builtin_bswap32(v.x);
+    A.w[2] = __builtin_amdgcn_alignbit(A.w[2], A.w[1], 31) ^ __builtin_bswap32(v.y);
+    A.w[1] = __builtin_amdgcn_alignbit(A.w[1], A.w[0], 31) ^ __builtin_bswap32(v.z);
+    A.w[0] = (A.w[0] << 1) ^ __builtin_bswap32(v.w);
+}
+// t * x^128 folded onto (lo, hi) = the words 128 and 96 bit positions below t
+__device__ inline void crc16_fold128(uint32_t t, uint32_t &lo, uint32_t &hi)
+{
+    lo ^= (t << 8) ^ (t << 2) ^ (t << 1);
+    hi ^= (t >> 24) ^ (t >> 30) ^ (t >> 31);
+}
+__device__ inline void crc16_acc_fold(CrcAcc &A)
+{
+    crc16_fold128(A.w[4], A.w[0], A.w[1]);
+    A.w[4] = 0;
+}
+// A lane's pieces as one remainder: n0 holds the newest step (weight 1), n1 the step before it (x^8192), n2, n3;
+// Horner's rule with x^8192 on the unreduced words, the words from bit 128 up folded down, then the piece
+// arithmetic above.  q: remainder modulo Q (below 2^15); parity: of the lane's message (low bit).  WORDS = 6 holds
+// any accumulators (160 bits and three multiplications by x^8 + ...); 5 is enough when no accumulator has more
+// than three steps behind it (131 + 24 bits).
+template <int WORDS>
+__device__ inline void crc16_acc_merge(const CrcAcc &n0, const CrcAcc &n1, const CrcAcc &n2, const CrcAcc &n3, uint32_t &q,
+                                       uint32_t &parity)
+{
+    static_assert(WORDS == 5 || WORDS == 6, "");
+    uint32_t h[6] = {n3.w[0], n3.w[1], n3.w[2], n3.w[3], n3.w[4], 0u};
+    auto horner = [&](const CrcAcc &n) {   // h = h * (x^8 + x^4 + x) + n
+#pragma unroll
+        for (int i = WORDS - 1; i >= 1; --i)
+            h[i] = __builtin_amdgcn_alignbit(h[i], h[i - 1], 24) ^ __builtin_amdgcn_alignbit(h[i], h[i - 1], 28) ^
+                   __builtin_amdgcn_alignbit(h[i], h[i - 1], 31) ^ (i < 5 ? n.w[i] : 0u);
+        h[0] = (h[0] << 8) ^ (h[0] << 4) ^ (h[0] << 1) ^ n.w[0];
+    };
+    horner(n2); horner(n1); horner(n0);
+    if (WORDS == 6) crc16_fold128(h[5], h[1], h[2]);
+    crc16_fold128(h[4], h[0], h[1]);
+    parity = __popc(h[0]) + __popc(h[1]) + __popc(h[2]) + __popc(h[3]);
+    q = crc16_words_q(h[3], h[2], h[1], h[0]);
+}
+__device__ inline uint32_t crc16_acc_flush(const CrcAcc &n0, const CrcAcc &n1, const CrcAcc &n2, const CrcAcc &n3)
+{
+    uint32_t q, parity;
+    crc16_acc_merge<6>(n0, n1, n2, n3, q, parity);
+    return crc16_join(q, parity);
+}
+
+// The remainders of the 64 lanes of a wave as one CRC-16, the same in every lane: lane l's message stands
+// 128 * (63 - l) bit positions above lane 63's.  Modulo Q, x^128 = x^8 + x^2 + x, x^256 = x^4 + x, x^512 = x^8 + x^2,
+// x^1024 = x^4 + x^2 + x, x^2048 = x^8 + x^4 + x^2: four doubling steps inside rows of 16 lanes (data-parallel
+// moves, no LDS), the four row results joined on the scalar side; modulo x + 1 every weight is 1.
+template <int CTRL>
+__device__ inline uint32_t crc16_dpp(uint32_t v)   // lanes without a source read zero
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ inline uint32_t crc16_wave_join(uint32_t q, uint32_t parity)
+{
+    uint32_t t;
+    t = crc16_dpp<0x111>(q); q = crc16_fold15(q ^ (t << 8) ^ (t << 2) ^ (t << 1));   // row_shr:1
+    t = crc16_dpp<0x112>(q); q = crc16_fold15(q ^ (t << 4) ^ (t << 1));              // row_shr:2
+    t = crc16_dpp<0x114>(q); q = crc16_fold15(q ^ (t << 8) ^ (t << 2));              // row_shr:4
+    t = crc16_dpp<0x118>(q); q = crc16_fold15(q ^ (t << 4) ^ (t << 2) ^ (t << 1));   // row_shr:8
+    uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)q, 15);
+#pragma unroll
+    for (int row = 1; row < 4; ++row)
+        r = crc16_fold15((r << 8) ^ (r << 4) ^ (r << 2)) ^ (uint32_t)__builtin_amdgcn_readlane((int)q, 16 * row + 15);
+    const uint32_t odd = (uint32_t)__popcll(__ballot((parity & 1u) != 0));
+    return crc16_join(r, odd);
+}
+
+// Bytes [from, to) of a 16-byte piece, the rest zero.
+__device__ inline uint4 crc16_keep_bytes(uint4 v, uint32_t from, uint32_t to)
+{
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int32_t lo = (int32_t)from - 4 * i, hi = (int32_t)to - 4 * i;   // kept byte range inside word i
+        uint32_t m = 0xFFFFFFFFu;
+        if (lo >= 4 || hi <= 0) m = 0;
+        else {
+            if (lo > 0) m &= 0xFFFFFFFFu << (8 * lo);
+            if (hi < 4) m &= 0xFFFFFFFFu >> (8 * (4 - hi));
+        }
+        w[i] &= m;
+    }
+    return uint4{w[0], w[1], w[2], w[3]};
+}
+
+// The first n bytes (0 .. 16) of a piece given as message words (most significant first), the rest zero.
+__device__ inline void crc16_keep_head(uint32_t n, uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3)
+{
+    uint32_t *w[4] = {&w0, &w1, &w2, &w3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int32_t nb = (int32_t)n - 4 * i;   // bytes of word i that are kept
+        const uint32_t m = nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (4 - nb));
+        *w[i] &= m;
+    }
+}
+
+// Cut records of the scan.  k_scan_tiles has every byte in registers once; it keeps the wide accumulators of the
+// CRC-16 running while it searches, and cuts the running message at every sync code it sees (validated or not) and
+// at the end of the 16 KiB a wave steps over.  A cut leaves a record: where it is, and the CRC-16 of the bytes since
+// the cut before it, zero-padded to the end of the cut's 1 KiB step.  The CRC-16 of a span between two candidates
+// (both are sync codes, so both are cuts) is then a few multiplications by powers of x over the records in between
+// (k_span_crc): the compressed bytes are not read a second time for it.
+//   segrec[range * kSegSlots + 0]      = number of cuts in the range (kSegOverflow: more than fit) | CRC-16 up to the range's end << 16
+//   segrec[range * kSegSlots + 1 + i]  = offset of cut i inside the range | CRC-16 up to the cut << 16
+constexpr uint32_t kSegRangeLog2 = 14, kSegRangeBytes = 1u << kSegRangeLog2;   // one wave's share of a scan tile
+constexpr uint32_t kSegSlots = 32;
+constexpr uint32_t kSegOverflow = 0xFFFFu;
+static_assert(kSegRangeBytes * 4 == kScanTileBytes, "a scan tile is four waves' ranges");
+
 // ------------------------------------------------------------------ scan ---
 
 constexpr uint32_t kChunkBytes = 1024;                            // one wave step: 64 lanes x 16 bytes
@@ -177,7 +411,7 @@ __device__ inline int find_stream_in(const StreamDev *streams, uint32_t lo, uint
 __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ in, uint64_t in_bytes,
                                                     const StreamDev *__restrict__ streams, uint32_t n_streams,
                                                     uint16_t *__restrict__ mask16, uint64_t *__restrict__ bitmap64,
-                                                    uint32_t *__restrict__ tile_count)
+                                                    uint32_t *__restrict__ tile_count, uint32_t *__restrict__ segrec)
 {
     __shared__ uint32_t s_mask[kScanTileBytes / 32];
     __shared__ uint16_t s_hits[kHitCap];
@@ -205,6 +439,19 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
         const StreamDev s = streams[si];
         FrameHdr h;
         if (parse_frame_header(in + g, s.in_off + s.in_len - g, s, h)) atomicOr(&s_mask[off >> 5], 1u << (off & 31));
+    };
+
+    // CRC-16 of the bytes since the last cut: accumulator k takes the chunks whose index is k modulo 4
+    CrcAcc acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) crc16_acc_clear(acc[k]);
+    uint32_t *const rec = segrec + ((uint64_t)blockIdx.x * 4 + wave) * kSegSlots;
+    uint32_t ncuts = 0;
+    // CRC-16 of everything accumulated, as if the message ended with chunk k (index modulo 4): the same in every lane
+    auto wave_flush = [&](int k) {
+        uint32_t q, parity;
+        crc16_acc_merge<5>(acc[k], acc[(k + 3) & 3], acc[(k + 2) & 3], acc[(k + 1) & 3], q, parity);
+        return crc16_wave_join(q, parity);
     };
 
     const uint32_t field = 0xF8FFu;
@@ -242,6 +489,7 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
                 uint32_t hits = 0;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) hits |= (uint32_t)((m[j] >> lane) & 1) << j;
+                const uint32_t my_hits = hits;
                 if (hits) {
                     uint32_t slot = atomicAdd(&s_nhits, (uint32_t)__builtin_popcount(hits));
                     const uint32_t off0 = (chunk0 + k) * kChunkBytes + lane * kGranule;
@@ -252,8 +500,37 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
                         ++slot;
                     }
                 }
+                // cut the running CRC-16 at every hit, in stream order: the bytes of this chunk before the hit end a
+                // message, the rest begins the next one
+                crc16_acc_step(acc[k], uint4{0u, 0u, 0u, 0u});
+                uint32_t c0 = __builtin_bswap32(v[k].x), c1 = __builtin_bswap32(v[k].y), c2 = __builtin_bswap32(v[k].z),
+                         c3 = __builtin_bswap32(v[k].w);   // the chunk's bytes not yet added, as message words
+                for (uint64_t hl = __ballot(my_hits != 0); hl; hl &= hl - 1) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(hl);
+                    for (uint32_t hb = (uint32_t)__builtin_amdgcn_readlane((int)my_hits, (int)l); hb; hb &= hb - 1) {
+                        const uint32_t o = (uint32_t)__builtin_ctz(hb);
+                        uint32_t p0 = c0, p1 = c1, p2 = c2, p3 = c3;   // what of it lies before the hit
+                        if (lane == l) crc16_keep_head(o, p0, p1, p2, p3);
+                        if (lane > l) p0 = p1 = p2 = p3 = 0;
+                        c0 ^= p0; c1 ^= p1; c2 ^= p2; c3 ^= p3;
+                        acc[k].w[3] ^= p0; acc[k].w[2] ^= p1; acc[k].w[1] ^= p2; acc[k].w[0] ^= p3;
+                        const uint32_t crc = wave_flush(k);
+                        if (ncuts < kSegSlots - 1 && lane == 0)
+                            rec[1 + ncuts] = ((round * 4 + k) * kChunkBytes + l * kGranule + o) | (crc << 16);
+                        ++ncuts;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) crc16_acc_clear(acc[q]);
+                    }
+                }
+                acc[k].w[3] ^= c0; acc[k].w[2] ^= c1; acc[k].w[1] ^= c2; acc[k].w[0] ^= c3;
+            } else {
+                crc16_acc_step(acc[k], v[k]);
             }
         }
+    }
+    {
+        const uint32_t crc = wave_flush(3);
+        if (lane == 0) rec[0] = (ncuts < kSegSlots ? ncuts : kSegOverflow) | (crc << 16);
     }
     __syncthreads();
     const uint32_t nh = s_nhits;
@@ -408,163 +685,7 @@ __global__ void k_stream_ranges(StreamDev *streams, uint32_t n_streams, const ui
     streams[s].pending = 0;
 }
 
-// ---------------------------------------------------------------- CRC-16 ---
-
-// a * b in GF(2)[x] modulo x^16 + x^15 + x^2 + 1
-__device__ inline uint32_t gf_mulmod(uint32_t a, uint32_t b)
-{
-    uint32_t r = 0;
-#pragma unroll
-    for (int i = 15; i >= 0; --i) {
-        r <<= 1;
-        if (r & 0x10000) r ^= 0x18005;
-        if ((b >> i) & 1) r ^= a;
-    }
-    return r & 0xFFFF;
-}
-
-// x^(8n) mod P, from a table of x^(8 * 2^k)
-__device__ inline uint32_t gf_xpow8(uint32_t n, const uint16_t *pow2)
-{
-    uint32_t r = 1;
-    for (int k = 0; n; ++k, n >>= 1)
-        if (n & 1) r = gf_mulmod(r, pow2[k]);
-    return r;
-}
-
-// CRC-16 of `len` bytes followed by `after` zero-weighted bytes: crc(msg) * x^(8*after)
-__device__ inline uint32_t crc16_shift(uint32_t crc, uint32_t after, const uint16_t *pow2)
-{
-    return after ? gf_mulmod(crc, gf_xpow8(after, pow2)) : crc;
-}
-
-// pow2[k] = x^(8 * 2^k) mod P, for gf_xpow8
-__device__ inline void crc16_pow_table(uint16_t *pow2)
-{
-    if (threadIdx.x == 0) {
-        uint32_t p = 0x100;  // x^8
-        for (int k = 0; k < 32; ++k) { pow2[k] = (uint16_t)p; p = gf_mulmod(p, p); }
-    }
-}
-
-// Lookup tables of k_crc16_spans, built once per handle (uint16 entries):
-//   lanew[l]     (64)        x^(8 * 16 * (63 - l))
-//   remw[r]      (16)        x^(8 * r)
-//   pow2[k]      (32)        x^(8 * 2^k), for gf_xpow8
-//   inv[r]       (16)        x^(-8 * r): x has order 32767 modulo 0x18005 = (x + 1)(x^15 + x + 1)
-constexpr int kCrcLane = 0, kCrcRem = kCrcLane + 64,
-              kCrcPow2 = kCrcRem + 16, kCrcInv = kCrcPow2 + 32, kCrcTableEntries = kCrcInv + 16;
-
-__global__ void k_crc16_build_tables(uint16_t *t)
-{
-    __shared__ uint16_t s_pow2[32];
-    crc16_pow_table(s_pow2);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries; i += blockDim.x) {
-        uint32_t v;
-        if (i < (uint32_t)kCrcRem) {
-            v = gf_xpow8(16 * (63 - (i - kCrcLane)), s_pow2);
-        } else if (i < (uint32_t)kCrcPow2) {
-            v = gf_xpow8(i - kCrcRem, s_pow2);
-        } else if (i < (uint32_t)kCrcInv) {
-            v = s_pow2[i - kCrcPow2];
-        } else {
-            v = gf_xpow8((32767u - (i - kCrcInv)) % 32767u, s_pow2);
-        }
-        t[i] = (uint16_t)v;
-    }
-}
-
-// CRC-16 of the 16 bytes of a vector taken as a message of its own (init 0), without tables: byte-table
-// lookups from 64 lanes collide in the LDS banks and made the kernel LDS-bound.
-// The polynomial factors: x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1).  Modulo x + 1 a polynomial is the
-// parity of its bits.  Modulo Q = x^15 + x + 1, x^15 = x + 1, so a high part h (bits 15 and up) folds down as
-// h + h*x; x^32 = x^4 + x^2, x^64 = x^8 + x^4, x^96 = x^12 + x^10 + x^8 + x^6 and x^16 = x^2 + x.  The
-// remainder r modulo Q and the parity p of the message give the CRC as r + c*Q with c = p + parity(r)
-// (Q has three terms, so adding it flips the parity).
-__device__ inline uint32_t crc16_fold15(uint32_t w)   // congruent to w modulo Q; below 2^18 for any w, below 2^15 for w < 2^19
-{
-    const uint32_t h = w >> 15;
-    return (w & 0x7FFFu) ^ h ^ (h << 1);
-}
-__device__ inline uint32_t crc16_piece(const uint4 v)
-{
-    const uint32_t parity = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-    // the message's four words, first byte in the highest bits
-    const uint32_t a = crc16_fold15(__builtin_bswap32(v.x)), b = crc16_fold15(__builtin_bswap32(v.y)),
-                   c = crc16_fold15(__builtin_bswap32(v.z)), d = crc16_fold15(__builtin_bswap32(v.w));
-    uint32_t t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d;   // < 2^30
-    t = crc16_fold15(t);             // < 2^17
-    t = (t << 2) ^ (t << 1);         // times x^16: the CRC is the remainder of message * x^16
-    t = crc16_fold15(t);             // < 2^15: the remainder modulo Q
-    const uint32_t flip = (parity + __popc(t)) & 1u;
-    return t ^ (0x8003u & (0u - flip));
-}
-
-// The same for a message of four words given most significant first.
-__device__ inline uint32_t crc16_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
-{
-    const uint32_t parity = __popc(w0) + __popc(w1) + __popc(w2) + __popc(w3);
-    const uint32_t a = crc16_fold15(w0), b = crc16_fold15(w1), c = crc16_fold15(w2), d = crc16_fold15(w3);
-    uint32_t t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d;
-    t = crc16_fold15(t);
-    t = (t << 2) ^ (t << 1);
-    t = crc16_fold15(t);
-    const uint32_t flip = (parity + __popc(t)) & 1u;
-    return t ^ (0x8003u & (0u - flip));
-}
-
-// Wide accumulators.  A lane of a wave that steps over a message 1 KiB at a time sees pieces that are 8192 bit
-// positions apart, and modulo P = x^16 + x^15 + x^2 + 1 (x has order 32767)
-//     x^32768 = x,     x^8192 = x^8 + x^4 + x,     x^128 = x^8 + x^2 + x
-// (relations with an even number of terms hold modulo x + 1 as well as modulo x^15 + x + 1, so modulo P).  Pieces
-// four steps apart therefore differ by a factor x: a lane keeps four accumulators, one per step index modulo 4,
-// and adds a piece to its accumulator as  A = A * x + piece  on the unreduced 128-bit value (a one-bit shift over
-// five words and four XORs) instead of reducing every piece to 16 bits.  A fifth word takes the bits shifted out:
-// 32 steps per accumulator, then crc16_acc_fold brings it back to 128 bits (x^128 above).  The four accumulators
-// are joined by Horner's rule with x^8192 and reduced once per message (crc16_acc_flush).
-struct CrcAcc { uint32_t w[5]; };   // w[0] least significant
-__device__ inline void crc16_acc_clear(CrcAcc &A) { A.w[0] = A.w[1] = A.w[2] = A.w[3] = A.w[4] = 0; }
-__device__ inline void crc16_acc_step(CrcAcc &A, const uint4 v)   // v: 16 message bytes in memory order
-{
-    A.w[4] = __builtin_amdgcn_alignbit(A.w[4], A.w[3], 31);
-    A.w[3] = __builtin_amdgcn_alignbit(A.w[3], A.w[2], 31) ^ __builtin_bswap32(v.x);
-    A.w[2] = __builtin_amdgcn_alignbit(A.w[2], A.w[1], 31) ^ __builtin_bswap32(v.y);
-    A.w[1] = __builtin_amdgcn_alignbit(A.w[1], A.w[0], 31) ^ __builtin_bswap32(v.z);
-    A.w[0] = (A.w[0] << 1) ^ __builtin_bswap32(v.w);
-}
-__device__ inline void crc16_acc_add(CrcAcc &A, const uint4 v)    // a piece of the accumulator's newest step, no shift
-{
-    A.w[3] ^= __builtin_bswap32(v.x); A.w[2] ^= __builtin_bswap32(v.y);
-    A.w[1] ^= __builtin_bswap32(v.z); A.w[0] ^= __builtin_bswap32(v.w);
-}
-// t * x^128 folded onto (lo, hi) = the words 128 and 96 bit positions below t
-__device__ inline void crc16_fold128(uint32_t t, uint32_t &lo, uint32_t &hi)
-{
-    lo ^= (t << 8) ^ (t << 2) ^ (t << 1);
-    hi ^= (t >> 24) ^ (t >> 30) ^ (t >> 31);
-}
-__device__ inline void crc16_acc_fold(CrcAcc &A)
-{
-    crc16_fold128(A.w[4], A.w[0], A.w[1]);
-    A.w[4] = 0;
-}
-// CRC-16 of a lane's pieces: n0 holds the newest step (weight 1), n1 the step before it (x^8192), n2, n3.
-__device__ inline uint32_t crc16_acc_flush(const CrcAcc &n0, const CrcAcc &n1, const CrcAcc &n2, const CrcAcc &n3)
-{
-    uint32_t h[6] = {n3.w[0], n3.w[1], n3.w[2], n3.w[3], n3.w[4], 0u};
-    auto horner = [&](const CrcAcc &n) {   // h = h * (x^8 + x^4 + x) + n
-#pragma unroll
-        for (int i = 5; i >= 1; --i)
-            h[i] = __builtin_amdgcn_alignbit(h[i], h[i - 1], 24) ^ __builtin_amdgcn_alignbit(h[i], h[i - 1], 28) ^
-                   __builtin_amdgcn_alignbit(h[i], h[i - 1], 31) ^ (i < 5 ? n.w[i] : 0u);
-        h[0] = (h[0] << 8) ^ (h[0] << 4) ^ (h[0] << 1) ^ n.w[0];
-    };
-    horner(n2); horner(n1); horner(n0);
-    crc16_fold128(h[5], h[1], h[2]);
-    crc16_fold128(h[4], h[0], h[1]);
-    return crc16_words(h[3], h[2], h[1], h[0]);
-}
+// ---------------------------------------------------------- CRC-16 spans ---
 
 // CRC-16 of every candidate span [goff[r], goff[r] + seglen[r]).  One wave per span at a time (waves
 // stride over the spans).  The span is cut into 16-byte pieces on 16-byte boundaries; the bytes of the
@@ -574,15 +695,16 @@ __device__ inline uint32_t crc16_acc_flush(const CrcAcc &n0, const CrcAcc &n1, c
 // accumulators (crc16_acc_step); at the end of the span a lane reduces its accumulators to one remainder,
 // and the 64 remainders are weighted by lane and XOR-ed.  The next step's piece (or the first piece of the
 // wave's next span) is loaded before the current one is processed.
+// With `list`, the spans are those of the candidates list[0 .. *list_count) only.
 __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__ in, CandArrays c, uint32_t n_cand,
-                                                     const uint16_t *__restrict__ tables)
+                                                     const uint16_t *__restrict__ tables, const uint32_t *__restrict__ list = nullptr,
+                                                     const uint32_t *__restrict__ list_count = nullptr)
 {
-    __shared__ __align__(16) uint16_t s_t[kCrcTableEntries];
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries / 2; i += blockDim.x)
+    __shared__ __align__(16) uint16_t s_t[kCrcCoreEntries];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcCoreEntries / 2; i += blockDim.x)
         reinterpret_cast<uint32_t *>(s_t)[i] = reinterpret_cast<const uint32_t *>(tables)[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t lanew = s_t[kCrcLane + lane];
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
 
     struct Span { uint64_t A; uint32_t lead, npieces, steps, pad, trail; };
@@ -606,31 +728,20 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
         const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)g.pad;
         return (j >= 0 && g.npieces) ? *reinterpret_cast<const uint4 *>(in + g.A + (uint64_t)j * 16) : uint4{0u, 0u, 0u, 0u};
     };
-    // keeps bytes [from, to) of a piece
-    auto keep_bytes = [](uint4 v, uint32_t from, uint32_t to) {
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int32_t lo = (int32_t)from - 4 * i, hi = (int32_t)to - 4 * i;   // kept byte range inside word i
-            uint32_t m = 0xFFFFFFFFu;
-            if (lo >= 4 || hi <= 0) m = 0;
-            else {
-                if (lo > 0) m &= 0xFFFFFFFFu << (8 * lo);
-                if (hi < 4) m &= 0xFFFFFFFFu >> (8 * (4 - hi));
-            }
-            w[i] &= m;
-        }
-        return uint4{w[0], w[1], w[2], w[3]};
+    if (list) n_cand = *list_count;
+    auto span_of = [&](uint32_t i) {
+        const uint32_t r = list ? list[i] : i;
+        return geometry(c.goff[r], c.seglen[r]);
     };
-
-    uint32_t r = uniform32(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (r >= n_cand) return;
-    Span g = geometry(c.goff[r], c.seglen[r]);
+    uint32_t i = uniform32(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (i >= n_cand) return;
+    Span g = span_of(i);
     uint4 cur = load_piece(g, 0);
-    while (r < n_cand) {
-        const uint32_t r_next = r + waves;
+    while (i < n_cand) {
+        const uint32_t r = uniform32(list ? list[i] : i);
+        const uint32_t r_next = i + waves;
         Span g_next = g;
-        if (r_next < n_cand) g_next = geometry(c.goff[r_next], c.seglen[r_next]);
+        if (r_next < n_cand) g_next = span_of(r_next);
         CrcAcc a0, a1, a2, a3;   // by the step's distance from the span's last step, modulo 4
         crc16_acc_clear(a0); crc16_acc_clear(a1); crc16_acc_clear(a2); crc16_acc_clear(a3);
         const uint32_t steps = uniform32(g.steps);
@@ -640,8 +751,8 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
             if (t + 1 < steps) nxt = load_piece(g, t + 1);
             else if (more) nxt = load_piece(g_next, 0);
             const int32_t j = (int32_t)(t * 64 + lane) - (int32_t)g.pad;
-            if (t == 0 && g.lead && j == 0) cur = keep_bytes(cur, g.lead, 16);
-            if (t + 1 == steps && g.trail && j == (int32_t)g.npieces - 1) cur = keep_bytes(cur, 0, 16 - g.trail);
+            if (t == 0 && g.lead && j == 0) cur = crc16_keep_bytes(cur, g.lead, 16);
+            if (t + 1 == steps && g.trail && j == (int32_t)g.npieces - 1) cur = crc16_keep_bytes(cur, 0, 16 - g.trail);
             switch ((steps - 1 - t) & 3u) {
             case 0: crc16_acc_step(a0, cur); break;
             case 1: crc16_acc_step(a1, cur); break;
@@ -651,14 +762,75 @@ __global__ __launch_bounds__(256) void k_crc16_spans(const uint8_t *__restrict__
             if ((t & 127u) == 127u) { crc16_acc_fold(a0); crc16_acc_fold(a1); crc16_acc_fold(a2); crc16_acc_fold(a3); }
             cur = nxt;
         }
-        uint32_t acc = crc16_acc_flush(a0, a1, a2, a3);
-        acc = gf_mulmod(acc, lanew);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc ^= __shfl_xor(acc, d);
+        uint32_t q, parity;
+        crc16_acc_merge<6>(a0, a1, a2, a3, q, parity);
+        const uint32_t acc = crc16_wave_join(q, parity);
         if (lane == 0) c.segcrc[r] = (uint16_t)(g.trail ? gf_mulmod(acc, s_t[kCrcInv + g.trail]) : acc);
-        r = r_next;
+        i = r_next;
         g = g_next;
     }
+}
+
+// CRC-16 of every candidate span from the scan's cut records, one thread per candidate.  A span that runs from one
+// candidate to the next starts and ends at a cut; the records of the cuts after its start, up to its end, each hold
+// the CRC-16 of the bytes since the cut before (zero-padded to the end of a 1 KiB step, which a multiplication by a
+// negative power of x takes out again), and  crc(A B) = crc(A) * x^(8 |B|) + crc(B).  Spans the records cannot
+// give (the last span of a stream ends at the stream's end, not at a cut; a range with more cuts than its slots
+// hold) are listed in fb_list for k_crc16_spans, which reads their bytes.
+__global__ __launch_bounds__(256) void k_span_crc(CandArrays c, uint32_t n_cand, const uint32_t *__restrict__ segrec,
+                                                  const uint16_t *__restrict__ tables, uint32_t *__restrict__ fb_list,
+                                                  uint32_t *__restrict__ fb_count)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_cand) return;
+    const uint64_t a = c.goff[r];
+    const uint32_t len = c.seglen[r];
+    if (len == 0) { c.segcrc[r] = 0; return; }
+    const uint64_t e = a + len;
+    bool ok = r + 1 < n_cand && c.goff[r + 1] == e;
+    uint32_t crc = 0;
+    if (ok) {
+        uint64_t range = a >> kSegRangeLog2;
+        const uint32_t *rec = segrec + range * kSegSlots;
+        uint32_t hdr = rec[0], n = hdr & 0xFFFFu, i = 1;
+        if (n == kSegOverflow) ok = false;
+        else {
+            const uint32_t off_a = (uint32_t)a & (kSegRangeBytes - 1);
+            while (i <= n && (rec[i] & 0xFFFFu) != off_a) ++i;   // the cut at the span's first byte
+            ok = i <= n;
+        }
+        uint64_t pos = a;
+        while (ok && pos < e) {
+            uint64_t b;
+            uint32_t v, pad;
+            if (i < n) {             // the next cut of this range
+                const uint32_t x = rec[++i], off = x & 0xFFFFu;
+                b = (range << kSegRangeLog2) + off;
+                v = x >> 16;
+                pad = 1024u - (off & 1023u);    // zero bytes between the cut and the end of its step
+            } else {                 // the rest of the range; go on in the next one
+                b = (range + 1) << kSegRangeLog2;
+                v = hdr >> 16;
+                pad = 0;
+                if (b < e) {
+                    ++range;
+                    rec += kSegSlots;
+                    hdr = rec[0]; n = hdr & 0xFFFFu; i = 0;
+                    if (n == kSegOverflow) ok = false;
+                }
+            }
+            if (b > e) { ok = false; break; }
+            if (pad) v = gf_mulmod(v, tables[kCrcInvPad + pad]);
+            if (crc) {
+                const uint32_t d = (uint32_t)(b - pos);   // at most a range
+                crc = gf_mulmod(gf_mulmod(crc, tables[kCrcPowHi + (d >> 7)]), tables[kCrcPowLo + (d & 127u)]);
+            }
+            crc ^= v;
+            pos = b;
+        }
+    }
+    if (ok) c.segcrc[r] = (uint16_t)crc;
+    else fb_list[atomicAdd(fb_count, 1u)] = r;
 }
 
 // --------------------------------------------------------------- resolve ---

@@ -31,7 +31,7 @@ struct flacgpu_handle {
     hipStream_t own_stream = nullptr;
     std::string err;
     // decode
-    flacgpu::DevBuf streams, results, mask, bitmap, tile_count, tile_base, group_sum, group_base, counter, crc_tables;
+    flacgpu::DevBuf streams, results, mask, bitmap, tile_count, tile_base, group_sum, group_base, counter, crc_tables, segrec;
     flacgpu::DevBuf goff, num, info, stream, len, status, segcrc, seglen, subpos, next;
     uint32_t cand_cap = 0;
     hipEvent_t ev[flacgpu::EV_COUNT] = {};
@@ -41,6 +41,7 @@ struct flacgpu_handle {
     flacgpu::HostPipe *pipe = nullptr;   // created by the first host-buffer call
     bool fixed = false;    // buffers are carved from a static workspace: never freed, never grown
     uint32_t n_cand = 0;   // state of the last scan, used by flacgpu_scan_frames
+    uint32_t n_reread = 0; // spans of the last scan whose CRC-16 took a second read of their bytes
     // encode
     flacgpu::DevBuf e_streams, e_plans, e_frames, e_crc_off, e_crc_len, e_crc, e_windows, e_md5_T, e_stats, e_hints, e_modes;
     hipStream_t md5_stream = nullptr;

@@ -255,9 +255,10 @@ typedef struct flacgpu_frame {
 
 /* Device time of the last decode/scan call, milliseconds (FLACGPU_FLAG_TIMING). */
 typedef struct flacgpu_timing {
-    float scan_ms;       /* sync search + header validation + CRC-8 (candidate mask)   */
+    float scan_ms;       /* sync search + header validation + CRC-8 (candidate mask),
+                            running CRC-16 cut at every sync code                       */
     float compact_ms;    /* prefix sum + ordered candidate list                         */
-    float crc16_ms;      /* CRC-16 of every candidate span                              */
+    float crc16_ms;      /* CRC-16 of every candidate span from the scan's records      */
     float resolve_ms;    /* span resolution + range checks                              */
     float skim_ms;       /* subframe start positions                                    */
     float decode_ms;     /* Rice + prediction + decorrelation + PCM packing             */
@@ -268,7 +269,9 @@ typedef struct flacgpu_timing {
     uint64_t out_bytes;
     uint32_t decode_classes;  /* decode kernel classes the batch used: bit (taps == 32) + 2 * arithmetic
                                  (0 = 24-bit multiplies, 1 = 32-bit, 2 = 64-bit sums, 3 = 16-bit pairs) */
-    uint32_t reserved;
+    uint32_t crc16_reread_spans;  /* candidate spans whose CRC-16 needed a second read of their bytes (the last
+                                     span of every stream, and spans through 16 KiB of input with more than 31
+                                     sync codes); every other span's CRC-16 comes out of the scan's single pass */
 } flacgpu_timing;
 
 /* Stream ordering (every entry point with a hip_stream argument).  hip_stream is a

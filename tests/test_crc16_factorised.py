@@ -102,3 +102,70 @@ def test_wide_accumulators_equal_crc16():
                 pieces = [bytes([0xFF] * 16)] * steps
             message = (b"".join(p + bytes(1008) for p in pieces[:-1])) + pieces[-1]
             assert lane_remainder(pieces) == oracle.crc16(message), (steps, kind)
+
+
+# ---- the scan's flush: five-word merge and the join over the lanes of a wave (crc16_acc_merge<5>, crc16_wave_join) ----
+
+def _merge_q(n0, n1, n2, n3, words):
+    """Remainder modulo x^15 + x + 1 (times x^16) and parity of a lane's accumulators."""
+    h = list(n3) + [0]
+    for n in (n2, n1, n0):
+        new = list(h)
+        for i in range(words - 1, 0, -1):
+            new[i] = (_alignbit(h[i], h[i - 1], 24) ^ _alignbit(h[i], h[i - 1], 28) ^ _alignbit(h[i], h[i - 1], 31)
+                      ^ (n[i] if i < 5 else 0))
+        new[0] = (((h[0] << 8) ^ (h[0] << 4) ^ (h[0] << 1)) & _M32) ^ n[0]
+        h = new
+    if words == 6:
+        h[1], h[2] = _fold128(h[5], h[1], h[2])
+    else:
+        assert h[5] == 0 and h[4] < 1 << 27     # 131 + 24 bits
+    h[0], h[1] = _fold128(h[4], h[0], h[1])
+    parity = sum(bin(w).count("1") for w in h[:4]) & 1
+    a, b, c, d = (_fold15(w) for w in (h[3], h[2], h[1], h[0]))
+    t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d
+    t = _fold15(t)
+    t = _fold15((t << 2) ^ (t << 1))
+    return t, parity
+
+
+def _wave_join(q, parity):
+    """q[l], parity[l] of 64 lanes; lane l stands 128 * (63 - l) bits above lane 63."""
+    q = list(q)
+
+    def shr(v, n):      # row_shr:n inside rows of 16 lanes, zero where there is no source
+        return [v[l - n] if (l % 16) >= n else 0 for l in range(64)]
+    for n, shifts in ((1, (8, 2, 1)), (2, (4, 1)), (4, (8, 2)), (8, (4, 2, 1))):
+        t = shr(q, n)
+        for l in range(64):
+            w = q[l]
+            for s in shifts:
+                w ^= t[l] << s
+            q[l] = _fold15(w)
+            assert q[l] < 1 << 15
+    r = q[15]
+    for row in range(1, 4):
+        r = _fold15((r << 8) ^ (r << 4) ^ (r << 2)) ^ q[16 * row + 15]
+    flip = (sum(parity) + bin(r).count("1")) & 1
+    return r ^ (0x8003 if flip else 0)
+
+
+def test_scan_flush_equals_crc16():
+    """A wave's worth of data: `chunks` consecutive KiB (at most 16, as between two cuts of the scan), accumulated
+    by chunk index modulo 4 and flushed as the scan kernel does."""
+    rng = np.random.default_rng(18)
+    for chunks in (1, 2, 3, 4, 5, 7, 8, 13, 16):
+        for start in (0, 1, 2, 3):           # chunk index (modulo 4) of the first chunk
+            data = bytes(rng.integers(0, 256, size=1024 * chunks).astype(np.uint8))
+            qs, ps = [], []
+            for lane in range(64):
+                acc = [[0] * 5 for _ in range(4)]
+                for c in range(chunks):
+                    _acc_step(acc[(start + c) & 3], data[1024 * c + 16 * lane: 1024 * c + 16 * lane + 16])
+                k = (start + chunks - 1) & 3
+                q, p = _merge_q(acc[k], acc[(k + 3) & 3], acc[(k + 2) & 3], acc[(k + 1) & 3], 5)
+                q6, p6 = _merge_q(acc[k], acc[(k + 3) & 3], acc[(k + 2) & 3], acc[(k + 1) & 3], 6)
+                assert (q, p) == (q6, p6)
+                qs.append(q)
+                ps.append(p)
+            assert _wave_join(qs, ps) == oracle.crc16(data), (chunks, start)

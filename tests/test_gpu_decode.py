@@ -465,3 +465,53 @@ def test_frame_range_shards_of_one_stream(decoder):
         assert np.array_equal(d_out.cpu().numpy()[: si.pcm_bytes], want)
         assert sum(r.frames_ok for r in res) == sum(r.frames for r in res) == ost.frames_ok
         assert sum(r.samples for r in res) == si.total_samples
+
+
+def _decode_arena(decoder, files, gap, gap_fill):
+    """Streams `gap` bytes apart (a multiple of 16) in an input buffer whose other bytes are gap_fill repeated."""
+    import torch
+    infos, audios = zip(*(split_file(f) for f in files))
+    in_offs, out_offs, pos, opos = [], [], gap, 0
+    for si, a in zip(infos, audios):
+        in_offs.append(pos)
+        pos += (len(a) + 15) // 16 * 16 + gap
+        out_offs.append(opos)
+        opos += (si.pcm_bytes + 63) // 64 * 64
+    host = np.frombuffer((gap_fill * (pos // len(gap_fill) + 1))[:pos], dtype=np.uint8).copy()
+    for a, o in zip(audios, in_offs):
+        host[o:o + len(a)] = np.frombuffer(a, dtype=np.uint8)
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.zeros(max(opos, 64), dtype=torch.uint8, device="cuda")
+    streams = decoder.make_streams((in_offs[i], len(audios[i]), out_offs[i], infos[i].pcm_bytes, infos[i])
+                                   for i in range(len(files)))
+    res = decoder.decode_batch_device(d_in, pos, d_out, max(opos, 64), streams)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    return [out[out_offs[i]: out_offs[i] + infos[i].pcm_bytes] for i in range(len(files))], list(res)
+
+
+def test_crc16_comes_out_of_the_scan(decoder):
+    """The frame CRC-16 is accumulated by the scan kernel in its single pass over the input and cut at every sync
+    code; only the last span of a stream (it ends at the stream's end, not at a sync code) is read a second time.
+    When 16 KiB of input hold more sync codes than a record has slots (here: the bytes between the streams are
+    nothing but sync codes), the spans through them are read again instead.  Either way every frame's CRC-16
+    must come out as the oracle's does, for spans of one byte of payload up to spans over several 16 KiB ranges."""
+    big = [(2, 16, 30000, 1152), (8, 24, 40000, 16384), (2, 16, 4096 * 9 + 5, 4096), (1, 16, 20000, 4608)]
+    small = [(1, 16, 9000, 192), (2, 8, 700, 16)]       # dozens of frames in 16 KiB: more cuts than a record holds
+    files = []
+    for i, (ch, bps, n, bs) in enumerate(big + small):
+        x = synth.pcm(1300 + i, n, ch, bps, 44100, bs)
+        f, _ = synth.encode(x, bps, 44100, synth.options(bs, 8))
+        files.append(bytes(f))
+    expect = [oracle_decode(*split_file(f)) for f in files]
+    for count, gap_fill, overflow in ((len(big), b"\x00", False), (len(big), b"\xff\xf8", True),
+                                      (len(big), b"\xff\xf9\x00", True), (len(files), b"\x00", True)):
+        pcms, res = _decode_arena(decoder, files[:count], 4096, gap_fill)
+        for p, r, (want, ost) in zip(pcms, res, expect):
+            assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples)
+            assert ost.frames_ok == ost.frames and np.array_equal(p, want)
+        reread = decoder.timing().crc16_reread_spans
+        if overflow:
+            assert reread > count
+        else:
+            assert 0 < reread <= count
