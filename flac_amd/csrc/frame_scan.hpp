@@ -211,14 +211,17 @@ __device__ inline uint32_t crc16_fold15(uint32_t w)   // congruent to w modulo Q
     const uint32_t h = w >> 15;
     return (w & 0x7FFFu) ^ h ^ (h << 1);
 }
-// Remainder modulo Q of a four-word message (most significant word first) times x^16; below 2^15.
+// Remainder modulo Q of a four-word message (most significant word first); below 2^17.
 __device__ inline uint32_t crc16_words_q(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
     const uint32_t a = crc16_fold15(w0), b = crc16_fold15(w1), c = crc16_fold15(w2), d = crc16_fold15(w3);
-    uint32_t t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d;   // < 2^30
-    t = crc16_fold15(t);             // < 2^17
-    t = (t << 2) ^ (t << 1);         // times x^16: the CRC is the remainder of message * x^16
-    return crc16_fold15(t);          // < 2^15: the remainder modulo Q
+    const uint32_t t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d;   // < 2^30
+    return crc16_fold15(t);          // < 2^17
+}
+// Times x^16 = x^2 + x modulo Q (the CRC is the remainder of message * x^16), reduced below 2^15; q < 2^17.
+__device__ inline uint32_t crc16_times_x16(uint32_t q)
+{
+    return crc16_fold15((q << 2) ^ (q << 1));
 }
 // The CRC from the remainder modulo Q and the message's parity (its low bit).
 __device__ inline uint32_t crc16_join(uint32_t q, uint32_t parity)
@@ -228,7 +231,7 @@ __device__ inline uint32_t crc16_join(uint32_t q, uint32_t parity)
 }
 __device__ inline uint32_t crc16_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
-    return crc16_join(crc16_words_q(w0, w1, w2, w3), __popc(w0) + __popc(w1) + __popc(w2) + __popc(w3));
+    return crc16_join(crc16_times_x16(crc16_words_q(w0, w1, w2, w3)), __popc(w0) + __popc(w1) + __popc(w2) + __popc(w3));
 }
 __device__ inline uint32_t crc16_piece(const uint4 v)   // 16 message bytes in memory order
 {
@@ -243,7 +246,7 @@ __device__ inline uint32_t crc16_piece(const uint4 v)   // 16 message bytes in m
 // and adds a piece to its accumulator as  A = A * x + piece  on the unreduced 128-bit value (a one-bit shift over
 // five words and four XORs) instead of reducing every piece to 16 bits.  A fifth word takes the bits shifted out:
 // 32 steps per accumulator, then crc16_acc_fold brings it back to 128 bits (x^128 above).  The four accumulators
-// are joined by Horner's rule with x^8192 and reduced once per message (crc16_acc_flush).
+// are joined by Horner's rule with x^8192 and reduced once per message (crc16_acc_merge).
 struct CrcAcc { uint32_t w[5]; };   // w[0] least significant
 __device__ inline void crc16_acc_clear(CrcAcc &A) { A.w[0] = A.w[1] = A.w[2] = A.w[3] = A.w[4] = 0; }
 __device__ inline void crc16_acc_step(CrcAcc &A, const uint4 v)   // v: 16 message bytes in memory order
@@ -267,7 +270,8 @@ __device__ inline void crc16_acc_fold(CrcAcc &A)
 }
 // A lane's pieces as one remainder: n0 holds the newest step (weight 1), n1 the step before it (x^8192), n2, n3;
 // Horner's rule with x^8192 on the unreduced words, the words from bit 128 up folded down, then the piece
-// arithmetic above.  q: remainder modulo Q (below 2^15); parity: of the lane's message (low bit).  WORDS = 6 holds
+// arithmetic above.  q: remainder modulo Q of the lane's message, without the CRC's factor x^16 (below 2^17);
+// parity: of the lane's message (low bit).  WORDS = 6 holds
 // any accumulators (160 bits and three multiplications by x^8 + ...); 5 is enough when no accumulator has more
 // than three steps behind it (131 + 24 bits).
 template <int WORDS>
@@ -289,35 +293,29 @@ __device__ inline void crc16_acc_merge(const CrcAcc &n0, const CrcAcc &n1, const
     parity = __popc(h[0]) + __popc(h[1]) + __popc(h[2]) + __popc(h[3]);
     q = crc16_words_q(h[3], h[2], h[1], h[0]);
 }
-__device__ inline uint32_t crc16_acc_flush(const CrcAcc &n0, const CrcAcc &n1, const CrcAcc &n2, const CrcAcc &n3)
-{
-    uint32_t q, parity;
-    crc16_acc_merge<6>(n0, n1, n2, n3, q, parity);
-    return crc16_join(q, parity);
-}
-
 // The remainders of the 64 lanes of a wave as one CRC-16, the same in every lane: lane l's message stands
 // 128 * (63 - l) bit positions above lane 63's.  Modulo Q, x^128 = x^8 + x^2 + x, x^256 = x^4 + x, x^512 = x^8 + x^2,
 // x^1024 = x^4 + x^2 + x, x^2048 = x^8 + x^4 + x^2: four doubling steps inside rows of 16 lanes (data-parallel
-// moves, no LDS), the four row results joined on the scalar side; modulo x + 1 every weight is 1.
+// moves, no LDS), the four row results joined on the scalar side, where the CRC's factor x^16 goes in as well;
+// modulo x + 1 every weight is 1.
 template <int CTRL>
 __device__ inline uint32_t crc16_dpp(uint32_t v)   // lanes without a source read zero
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-__device__ inline uint32_t crc16_wave_join(uint32_t q, uint32_t parity)
+__device__ inline uint32_t crc16_wave_join(uint32_t q, uint32_t parity)   // q < 2^17: crc16_acc_merge's
 {
     uint32_t t;
-    t = crc16_dpp<0x111>(q); q = crc16_fold15(q ^ (t << 8) ^ (t << 2) ^ (t << 1));   // row_shr:1
-    t = crc16_dpp<0x112>(q); q = crc16_fold15(q ^ (t << 4) ^ (t << 1));              // row_shr:2
-    t = crc16_dpp<0x114>(q); q = crc16_fold15(q ^ (t << 8) ^ (t << 2));              // row_shr:4
-    t = crc16_dpp<0x118>(q); q = crc16_fold15(q ^ (t << 4) ^ (t << 2) ^ (t << 1));   // row_shr:8
+    t = crc16_dpp<0x111>(q); q ^= (t << 8) ^ (t << 2) ^ (t << 1);                    // row_shr:1, < 2^25
+    t = crc16_dpp<0x112>(q); q = crc16_fold15(q ^ (t << 4) ^ (t << 1));              // row_shr:2, < 2^29 before the fold
+    t = crc16_dpp<0x114>(q); q ^= (t << 8) ^ (t << 2);                               // row_shr:4, < 2^23
+    t = crc16_dpp<0x118>(q); q = crc16_fold15(q ^ (t << 4) ^ (t << 2) ^ (t << 1));   // row_shr:8, < 2^27 before the fold
     uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)q, 15);
 #pragma unroll
     for (int row = 1; row < 4; ++row)
         r = crc16_fold15((r << 8) ^ (r << 4) ^ (r << 2)) ^ (uint32_t)__builtin_amdgcn_readlane((int)q, 16 * row + 15);
     const uint32_t odd = (uint32_t)__popcll(__ballot((parity & 1u) != 0));
-    return crc16_join(r, odd);
+    return crc16_join(crc16_times_x16(r), odd);
 }
 
 // Bytes [from, to) of a 16-byte piece, the rest zero.

@@ -38,7 +38,7 @@ def test_piece_remainder_equals_crc16():
         assert piece_remainder(m) == oracle.crc16(m), m.hex()
 
 
-# ---- wide accumulators (crc16_acc_step / crc16_acc_fold / crc16_acc_flush of frame_scan.hpp), word by word ----
+# ---- wide accumulators (crc16_acc_step / crc16_acc_fold / crc16_acc_merge<6> + crc16_join of frame_scan.hpp), word by word ----
 
 _M32 = 0xFFFFFFFF
 
@@ -124,9 +124,7 @@ def _merge_q(n0, n1, n2, n3, words):
     parity = sum(bin(w).count("1") for w in h[:4]) & 1
     a, b, c, d = (_fold15(w) for w in (h[3], h[2], h[1], h[0]))
     t = (a << 12) ^ (a << 10) ^ (a << 8) ^ (a << 6) ^ (b << 8) ^ (b << 4) ^ (c << 4) ^ (c << 2) ^ d
-    t = _fold15(t)
-    t = _fold15((t << 2) ^ (t << 1))
-    return t, parity
+    return _fold15(t), parity            # below 2^17, without the CRC's factor x^16
 
 
 def _wave_join(q, parity):
@@ -135,17 +133,19 @@ def _wave_join(q, parity):
 
     def shr(v, n):      # row_shr:n inside rows of 16 lanes, zero where there is no source
         return [v[l - n] if (l % 16) >= n else 0 for l in range(64)]
-    for n, shifts in ((1, (8, 2, 1)), (2, (4, 1)), (4, (8, 2)), (8, (4, 2, 1))):
+    for n, shifts, fold in ((1, (8, 2, 1), False), (2, (4, 1), True), (4, (8, 2), False), (8, (4, 2, 1), True)):
         t = shr(q, n)
         for l in range(64):
             w = q[l]
             for s in shifts:
                 w ^= t[l] << s
-            q[l] = _fold15(w)
-            assert q[l] < 1 << 15
+            assert w < 1 << 32           # the kernel's registers
+            q[l] = _fold15(w) if fold else w
     r = q[15]
     for row in range(1, 4):
         r = _fold15((r << 8) ^ (r << 4) ^ (r << 2)) ^ q[16 * row + 15]
+    r = _fold15((r << 2) ^ (r << 1))     # times x^16
+    assert r < 1 << 15
     flip = (sum(parity) + bin(r).count("1")) & 1
     return r ^ (0x8003 if flip else 0)
 
