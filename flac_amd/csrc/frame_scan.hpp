@@ -120,15 +120,6 @@ __device__ inline int find_stream(const StreamDev *streams, uint32_t n, uint64_t
     return (g - s.in_off < s.in_len) ? (int)(lo - 1) : -1;
 }
 
-// byte-wise "is zero" detector: 0x80 in every byte of v that is zero (exact).
-__device__ inline uint32_t zero_bytes(uint32_t v)
-{
-    const uint32_t y = ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v;
-    return ~y & 0x80808080u;
-}
-// 0x80-per-byte mask -> 4-bit mask
-__device__ inline uint32_t movemask4(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xF; }
-
 // ---------------------------------------------------------------- CRC-16 arithmetic ---
 
 // a * b in GF(2)[x] modulo x^16 + x^15 + x^2 + 1
@@ -169,17 +160,14 @@ __device__ inline void crc16_pow_table(uint16_t *pow2)
 }
 
 // Lookup tables, built once per handle (uint16 entries):
-//   lanew[l]     (64)        x^(8 * 16 * (63 - l))
-//   remw[r]      (16)        x^(8 * r)
 //   pow2[k]      (32)        x^(8 * 2^k), for gf_xpow8
 //   inv[r]       (16)        x^(-8 * r): x has order 32767 modulo 0x18005 = (x + 1)(x^15 + x + 1)
 // and for k_span_crc, which joins the scan's cut records:
 //   invpad[n]    (1025)      x^(-8 * n), the zero bytes between a cut and the end of its 1 KiB step
 //   powlo[n]     (128)       x^(8 * n)
 //   powhi[n]     (129)       x^(8 * 128 * n): x^(8 * d) = powhi[d / 128] * powlo[d % 128] for d up to 16 KiB
-constexpr int kCrcLane = 0, kCrcRem = kCrcLane + 64, kCrcPow2 = kCrcRem + 16, kCrcInv = kCrcPow2 + 32,
-              kCrcCoreEntries = kCrcInv + 16, kCrcInvPad = kCrcCoreEntries, kCrcPowLo = kCrcInvPad + 1025,
-              kCrcPowHi = kCrcPowLo + 128, kCrcTableEntries = (kCrcPowHi + 129 + 1) & ~1;
+constexpr int kCrcPow2 = 0, kCrcInv = kCrcPow2 + 32, kCrcCoreEntries = kCrcInv + 16, kCrcInvPad = kCrcCoreEntries,
+              kCrcPowLo = kCrcInvPad + 1025, kCrcPowHi = kCrcPowLo + 128, kCrcTableEntries = (kCrcPowHi + 129 + 1) & ~1;
 
 __global__ void k_crc16_build_tables(uint16_t *t)
 {
@@ -188,9 +176,7 @@ __global__ void k_crc16_build_tables(uint16_t *t)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCrcTableEntries; i += blockDim.x) {
         uint32_t v;
-        if (i < (uint32_t)kCrcRem) v = gf_xpow8(16 * (63 - (i - kCrcLane)), s_pow2);
-        else if (i < (uint32_t)kCrcPow2) v = gf_xpow8(i - kCrcRem, s_pow2);
-        else if (i < (uint32_t)kCrcInv) v = s_pow2[i - kCrcPow2];
+        if (i < (uint32_t)kCrcInv) v = s_pow2[i - kCrcPow2];
         else if (i < (uint32_t)kCrcInvPad) v = gf_xpow8((32767u - (i - kCrcInv)) % 32767u, s_pow2);
         else if (i < (uint32_t)kCrcPowLo) v = gf_xpow8((32767u - (i - kCrcInvPad)) % 32767u, s_pow2);
         else if (i < (uint32_t)kCrcPowHi) v = gf_xpow8(i - kCrcPowLo, s_pow2);
@@ -199,9 +185,8 @@ __global__ void k_crc16_build_tables(uint16_t *t)
     }
 }
 
-// CRC-16 of the 16 bytes of a vector taken as a message of its own (init 0), without tables: byte-table
-// lookups from 64 lanes collide in the LDS banks and made the kernel LDS-bound.
-// The polynomial factors: x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1).  Modulo x + 1 a polynomial is the
+// CRC-16 of 128 message bits (init 0) without tables: byte-table lookups from 64 lanes collide in the LDS banks
+// and made the kernel LDS-bound.  The polynomial factors: x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1).  Modulo x + 1 a polynomial is the
 // parity of its bits.  Modulo Q = x^15 + x + 1, x^15 = x + 1, so a high part h (bits 15 and up) folds down as
 // h + h*x; x^32 = x^4 + x^2, x^64 = x^8 + x^4, x^96 = x^12 + x^10 + x^8 + x^6 and x^16 = x^2 + x.  The
 // remainder r modulo Q and the parity p of the message give the CRC as r + c*Q with c = p + parity(r)
@@ -229,15 +214,6 @@ __device__ inline uint32_t crc16_join(uint32_t q, uint32_t parity)
     const uint32_t flip = (parity + __popc(q)) & 1u;
     return q ^ (0x8003u & (0u - flip));
 }
-__device__ inline uint32_t crc16_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
-{
-    return crc16_join(crc16_times_x16(crc16_words_q(w0, w1, w2, w3)), __popc(w0) + __popc(w1) + __popc(w2) + __popc(w3));
-}
-__device__ inline uint32_t crc16_piece(const uint4 v)   // 16 message bytes in memory order
-{
-    return crc16_words(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
-}
-
 // Wide accumulators.  A lane of a wave that steps over a message 1 KiB at a time sees pieces that are 8192 bit
 // positions apart, and modulo P = x^16 + x^15 + x^2 + 1 (x has order 32767)
 //     x^32768 = x,     x^8192 = x^8 + x^4 + x,     x^128 = x^8 + x^2 + x

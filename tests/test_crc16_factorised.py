@@ -1,8 +1,9 @@
-"""The arithmetic of the table-free CRC-16 piece remainder used by k_crc16_spans
-(flac_amd/csrc/frame_scan.hpp, crc16_piece), restated in Python and checked against the oracle's
-bitwise CRC-16: x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1), so the remainder is rebuilt from the
-message's parity and its remainder modulo the trinomial, which folds with shifts and XORs only.
-The constants tested here are the ones the kernel uses."""
+"""The arithmetic of the table-free CRC-16 used by k_scan_tiles and k_crc16_spans (flac_amd/csrc/frame_scan.hpp:
+crc16_fold15, crc16_words_q, crc16_times_x16, crc16_join; the wide accumulators; the join over a wave's lanes),
+restated in Python word by word and checked against the oracle's bitwise CRC-16:
+x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1), so the remainder is rebuilt from the message's parity and its
+remainder modulo the trinomial, which folds with shifts and XORs only.  The constants tested here are the ones
+the kernels use."""
 import numpy as np
 
 from util import oracle
