@@ -170,3 +170,78 @@ def test_scan_flush_equals_crc16():
                 qs.append(q)
                 ps.append(p)
             assert _wave_join(qs, ps) == oracle.crc16(data), (chunks, start)
+
+
+# ---- the record scheme of k_scan_tiles / k_span_crc, on the CPU: cuts, zero padding, joins by powers of x ----
+
+_P = 0x18005
+
+
+def _gf_mulmod(a, b):
+    r = 0
+    for i in range(15, -1, -1):
+        r <<= 1
+        if r & 0x10000:
+            r ^= _P
+        if (b >> i) & 1:
+            r ^= a
+    return r & 0xFFFF
+
+
+def _xpow8(n):                      # x^(8 n) modulo P
+    r, base = 1, 0x100
+    while n:
+        if n & 1:
+            r = _gf_mulmod(r, base)
+        base = _gf_mulmod(base, base)
+        n >>= 1
+    return r
+
+
+def _scan_records(data, cuts):
+    """What the scan leaves for one input: per 16 KiB range the cuts inside it (offset in the range, CRC-16 of the
+    bytes since the cut before or the range's start, zero-padded to the end of the cut's 1 KiB step) and the CRC-16
+    from the last cut to the range's end."""
+    ranges = []
+    for base in range(0, len(data), 16384):
+        last, recs = base, []
+        for p in sorted(c for c in cuts if base <= c < base + 16384):
+            pad = 1024 - (p & 1023)
+            recs.append((p - base, oracle.crc16(data[last:p] + bytes(pad))))
+            last = p
+        ranges.append((recs, oracle.crc16(data[last:base + 16384])))
+    return ranges
+
+
+def _span_crc(ranges, a, e):
+    """k_span_crc's walk: CRC-16 of [a, e), both of them cuts, from the records."""
+    rng_i = a >> 14
+    recs, end_crc = ranges[rng_i]
+    i = [off for off, _ in recs].index(a & 16383)
+    crc, pos = 0, a
+    while pos < e:
+        if i + 1 < len(recs):
+            i += 1
+            off, v = recs[i]
+            b = (rng_i << 14) + off
+            v = _gf_mulmod(v, _xpow8(32767 - (1024 - (off & 1023))))      # x has order 32767: takes the padding out
+        else:
+            b, v = (rng_i + 1) << 14, end_crc
+            if b < e:
+                rng_i += 1
+                recs, end_crc = ranges[rng_i]
+                i = -1
+        assert b <= e
+        crc = _gf_mulmod(crc, _xpow8(b - pos)) ^ v if crc else v
+        pos = b
+    return crc
+
+
+def test_record_walk_equals_crc16():
+    rng = np.random.default_rng(19)
+    data = bytes(rng.integers(0, 256, size=5 * 16384).astype(np.uint8))
+    cuts = sorted(set(int(c) for c in rng.integers(0, len(data), size=40)) | {0, 1023, 1024, 16384, 3 * 16384 - 1, 3 * 16384})
+    ranges = _scan_records(data, cuts)
+    for n, a in enumerate(cuts):
+        for e in cuts[n + 1: n + 12]:
+            assert _span_crc(ranges, a, e) == oracle.crc16(data[a:e]), (a, e)
