@@ -390,12 +390,12 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
                                                     uint16_t *__restrict__ mask16, uint64_t *__restrict__ bitmap64,
                                                     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ segrec)
 {
-    __shared__ uint32_t s_mask[kScanTileBytes / 32];
+    __shared__ __align__(16) uint32_t s_mask[kScanTileBytes / 32];
     __shared__ uint16_t s_hits[kHitCap];
     __shared__ uint32_t s_nhits, s_count;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s_mask[tid * 8 + k] = 0;
+    for (int k = 0; k < 8; ++k) s_mask[k * 256 + tid] = 0;   // consecutive lanes, consecutive banks
     if (tid == 0) { s_nhits = 0; s_count = 0; }
     __syncthreads();
     const uint64_t tile_base = (uint64_t)blockIdx.x * kScanTileBytes;
@@ -534,9 +534,12 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
     // thread t owns granules 16t .. 16t+15 = mask words 8t .. 8t+7
     uint32_t nz = 0, cnt = 0;
     const uint64_t granule0 = (uint64_t)blockIdx.x * kTileGranules + tid * 16;
+    // (two 16-byte reads: word by word, lanes eight words apart would share four of the 32 banks)
+    const uint4 m_lo = reinterpret_cast<const uint4 *>(s_mask)[tid * 2], m_hi = reinterpret_cast<const uint4 *>(s_mask)[tid * 2 + 1];
+    const uint32_t m_own[8] = {m_lo.x, m_lo.y, m_lo.z, m_lo.w, m_hi.x, m_hi.y, m_hi.z, m_hi.w};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const uint32_t x = s_mask[tid * 8 + k];
+        const uint32_t x = m_own[k];
         if (x) {
             cnt += __builtin_popcount(x);
             if (x & 0xFFFFu) { mask16[granule0 + 2 * k] = (uint16_t)x; nz |= 1u << (2 * k); }
