@@ -848,6 +848,20 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     if (active && kind == 0) constval = br.read_signed(h.sbps);
     uint32_t pbits = 4, esc = 15, psamp = 0, parts_left = 0, part_rem = 0, k = 0, escw = 0;
     bool escaped = false, first_part = true;
+    // A constant subframe goes through the unrolled groups as a predicted one whose residual is always zero: order-1
+    // predictor with coefficient 1 and shift 0 over a history of the constant, Rice parameter 0, and a ring of
+    // all-one words, so that every code the lane reads there is the one-bit code of zero.  That spares the
+    // unrolled body a select per sample.  A constant the packed history cannot hold (17-bit side channels) keeps
+    // its lane, and with it the wave, in the generic groups.
+    const bool const_fast = kind != 0 || !DOT || (((uint32_t)constval + 0x8000u) >> 16) == 0;
+    if (active && kind == 0) {
+        coef[0] = 1;
+        if (DOT) cp[0] = pack_lo_hi(1, 0);
+#pragma unroll
+        for (int j = 0; j < U; ++j) ring[j] = constval;
+        for (uint32_t sl = 0; sl < kRingSlots; ++sl) br.ring[sl * 64] = 0xFFFFFFFFu;
+    }
+    const bool reads_stream = active && kind != 0;
 
     // Reads what follows the warm-up samples: LPC parameters (or the fixed
     // polynomial as coefficients) and the residual coding header.
@@ -907,13 +921,14 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     const uint32_t fast_bits = pair17 ? sbits - 1 : sbits;   // what a sample of an unrolled group has to fit
     const uint32_t half_fast = pair17 ? ((1u << fast_bits) >> 1) : half;
     uint32_t ovf = 0, govf = 0;
+    int32_t gmax = 0, gmin = 0;   // largest and smallest sample of an unrolled group (two three-operand instructions per pair of samples)
     // TILE16: columns of the current tile whose staged value (sample << wasted bits) does not fit 16 bits.  A
     // constant subframe with such a value marks every column for good.
     const uint32_t widemask_rest = (TILE16 && active && h.kind == 0 && ((((uint32_t)constval << h.wasted) + 0x8000u) >> 16)) ? 0xFFFFFFFFu : 0u;
     uint32_t widemask = widemask_rest;
     auto emit = [&](int32_t v, bool live, uint32_t col, auto always) {
         constexpr bool ALWAYS = decltype(always)::value;   // fast groups store from every lane: a dead lane's column is never written out
-        if (ALWAYS) govf |= (uint32_t)v + half_fast; else ovf |= (uint32_t)v + half;
+        if (ALWAYS) { gmax = max(gmax, v); gmin = min(gmin, v); } else ovf |= (uint32_t)v + half;
         const uint32_t x = (uint32_t)v << h.wasted;
         if (TILE16) {
             // generic groups store sample by sample; the unrolled groups store their packed pairs themselves
@@ -1268,9 +1283,9 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     // issue order: a round that follows a write-out waits for the write-out's stores as well.  So the round
     // between two groups runs before the write-out, not after it, and the stores have half a group to
     // complete before the next round (in the middle of the next group) has to wait for them.
-    ring_round(br, rf, active && status == kFrameOK);
-    ring_round(br, rf, active && status == kFrameOK);
-    ring_round(br, rf, active && status == kFrameOK);
+    ring_round(br, rf, reads_stream && status == kFrameOK);
+    ring_round(br, rf, reads_stream && status == kFrameOK);
+    ring_round(br, rf, reads_stream && status == kFrameOK);
     const bool trailing = __any(active && status == kFrameOK && kind == 2 && order >= bs);
     const uint32_t n_end = ((bs_max + U - 1) / U) * U + (trailing ? U : 0);
     for (uint32_t n0 = 0; n0 < n_end; n0 += U) {
@@ -1280,7 +1295,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
         const bool rice_on = on && kind == 2 && status == kFrameOK;
         const bool unstarted = active && status == kFrameOK && kind == 2 && !started;
         const bool simple = unstarted ? false
-                                      : (!on || kind == 0 ||
+                                      : (!on || (kind == 0 && const_fast && widemask_rest == 0) ||
                                          (rice_on && !escaped && part_rem >= (uint32_t)U && n0 + U <= bs && (!DOT || hist16)));
         bool redo = true;            // lanes the generic body below has to process
 #ifdef FLACGPU_DEBUG_NO_FAST
@@ -1298,6 +1313,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             // get it back afterwards.
             const uint32_t s_P = br.P;
             govf = 0;
+            gmax = 0; gmin = 0;
             if (DOT && !packs_ok) {
 #pragma unroll
                 for (int m = U - 1; m >= U - NT + 1; m -= 1) pk[m] = pack_lo_hi(ring[m], ring[m - 1]);
@@ -1333,23 +1349,23 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 constexpr int P = decltype(PC)::value;
                 const int32_t res = unzigzag(u);
                 int32_t pred;
+#ifdef FLACGPU_PROTO_NOPRED   // prototype build: what parsing and staging cost without the predictor (output is wrong)
+                if constexpr (DOT) { pred = 0; } else
+#endif
                 if constexpr (DOT) {
                     // pair i = taps 2i and 2i + 1 = samples n - 1 - 2i and n - 2 - 2i = pk[(n - 1 - 2i) % U]; two chains,
                     // and the pair with the newest sample, the only one that waits for the previous result, last
-                    int32_t sa = 0, sb = 0;
+                    // one chain, oldest pair first: only its last link waits for the previous sample
+                    int32_t sa = dot2_i16(pk[(P + 2 * U - 1 - 2 * (NP - 1)) % U], cp[NP - 1]);
 #pragma unroll
-                    for (int i = 1; i < NP; ++i) {
-                        const uint32_t x = pk[(P + 2 * U - 1 - 2 * i) % U];
-                        if (i & 1) sa = i == 1 ? dot2_i16(x, cp[i]) : dot2_i16(x, cp[i], sa);
-                        else sb = i == 2 ? dot2_i16(x, cp[i]) : dot2_i16(x, cp[i], sb);
-                    }
-                    pred = dot2_i16(pk[(P + U - 1) % U], cp[0], sa + sb) >> shift;
+                    for (int i = NP - 2; i >= 1; --i) sa = dot2_i16(pk[(P + 2 * U - 1 - 2 * i) % U], cp[i], sa);
+                    pred = dot2_i16(pk[(P + U - 1) % U], cp[0], sa) >> shift;
                 } else {
                     pred = predict([&](int j) { return ring[(P + U - 1 - j) % U]; });
                 }
                 int32_t decoded = (int32_t)((uint32_t)res + (uint32_t)pred);
                 asm volatile("" : "+v"(decoded));   // keeps the arithmetic out of a branch: the select below stays a v_cndmask
-                const int32_t v = rice_on ? decoded : constval;
+                const int32_t v = decoded;
                 ring[P] = v;
                 if constexpr (DOT) pk[P] = pack_lo_hi(v, ring[(P + U - 1) % U]);
                 emit(v, on, ((n0 + (uint32_t)P) & (kT - 1)), std::true_type{});
@@ -1394,9 +1410,10 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             // as 2^32 - 1 zeros), so the test never misses one; it is wrong the safe way now and then.
             redo = rice_on && (starved || longest_q > 31 - k);
 #endif
+            govf = ((uint32_t)gmax + half_fast) | ((uint32_t)gmin + half_fast);   // in range exactly when both ends are
             // a sample that does not fit 16 bits (less its wasted bits: the tile holds 16) was multiplied and staged as if it did
             if (pair17) redo = redo || (rice_on && (govf >> fast_bits));
-            else if (!redo) ovf |= govf;
+            else if (!redo && (rice_on || kind == 0)) ovf |= govf;   // a lane past the end of its block decoded noise
             if (rice_on && !redo) part_rem -= U;
             run_generic = __any(redo);
             packs_ok = !run_generic;
@@ -1430,7 +1447,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             if (U > (int)kT) restage(0);
             for (uint32_t n = n0; n < n0 + U; ++n) {
                 if (n != n0 && ((n - n0) % kRoundSteps) == 0)
-                    ring_round(br, rf, active && status == kFrameOK);
+                    ring_round(br, rf, reads_stream && status == kFrameOK);
                 if (U > (int)kT && n - n0 == kT) { flush(n0); restage((int)kT); }
                 const bool ok = active && status == kFrameOK && redo;
                 const bool live = ok && n < bs;
@@ -1476,7 +1493,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             }
         }
         const uint32_t done = n0 + U;
-        ring_round(br, rf, active && status == kFrameOK);
+        ring_round(br, rf, reads_stream && status == kFrameOK);
         if ((done & (kT - 1)) == 0 || done >= n_end) {
             const uint32_t t0 = (done - 1) & ~(kT - 1);   // tile that holds the group's last sample
             if (t0 < bs_max) flush(t0);

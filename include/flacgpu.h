@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define FLACGPU_API_VERSION 1
+#define FLACGPU_API_VERSION 2
+/* The version the library was built with; a binding compares it with the header it was generated from. */
+int flacgpu_api_version(void);
 
 /* ----------------------------------------------------------------- status */
 enum {
@@ -211,10 +213,26 @@ typedef struct flacgpu_options {
     uint32_t struct_size;     /* sizeof(flacgpu_options)                          */
     int32_t  device;          /* HIP device ordinal                               */
     uint32_t flags;           /* FLACGPU_FLAG_*                                   */
-    uint32_t reserved;
+    uint32_t output_format;   /* FLACGPU_OUT_*: how decoded samples are laid out  */
 } flacgpu_options;
 
-#define FLACGPU_FLAG_TIMING 1u   /* record HIP events around every kernel stage */
+#define FLACGPU_FLAG_TIMING     1u   /* record HIP events around every kernel stage */
+/* After the decode, hash every stream's PCM on the device (one lane per stream) and compare it with
+ * StreaminfoBlock.MD5Signature (flacmeta.go:664, :714); the outcome is flacgpu_stream_result.md5_status.
+ * Checked are streams with FLACGPU_OUT_PACKED output (the byte string the signature is defined over),
+ * a known TotalSamples, a signature that is not all zeros, sample_base 0, and every frame decoded. */
+#define FLACGPU_FLAG_VERIFY_MD5 2u
+
+/* Output layouts of the decoder.  PACKED is the default and the only one the MD5 check applies to. */
+#define FLACGPU_OUT_PACKED 0u   /* interleaved, ceil(bps / 8) bytes per sample, little-endian, sign-extended */
+#define FLACGPU_OUT_S32    1u   /* interleaved, 4 bytes per sample (int32 little-endian) whatever the stream's bps */
+#define FLACGPU_OUT_PLANAR 2u   /* one plane per channel: channel c of a stream starts at out_offset +
+                                   c * (out_capacity / channels rounded down to a multiple of 4), samples of
+                                   ceil(bps / 8) bytes in time order */
+
+#define FLACGPU_MD5_NOT_CHECKED 0u
+#define FLACGPU_MD5_MATCH       1u
+#define FLACGPU_MD5_MISMATCH    2u
 
 /* One stream of a batch.  All streams of a batch live in ONE device buffer
  * (d_in), in ascending, non-overlapping in_offset order; their PCM goes to ONE
@@ -223,18 +241,28 @@ typedef struct flacgpu_stream {
     uint64_t in_offset;       /* bytes from d_in to byte 0 of frame 0             */
     uint64_t in_length;       /* bytes of audio frames, below 2 GiB per entry (a longer stream is passed as
                                  several entries cut at SEEKTABLE offsets: frames carry their own numbers) */
-    uint64_t out_offset;      /* bytes from d_out to this stream's first sample   */
+    uint64_t out_offset;      /* bytes from d_out to the sample with index sample_base */
     uint64_t out_capacity;    /* bytes this stream may write                      */
+    uint64_t sample_base;     /* inter-channel index of the sample that lands at out_offset: 0 for a whole stream;
+                                 for a frame range cut at a seek point (SeekpointBlock.SampleNumber,
+                                 flacmeta.go:256-260) that point's sample number, so that a range decoded on its
+                                 own GPU needs an output region for its own samples only.  Frames that start
+                                 before it get FLACGPU_FRAME_RANGE. */
     flacgpu_streaminfo info;  /* from flacgpu_parse_metadata / Metadata.Read      */
 } flacgpu_stream;
 
 typedef struct flacgpu_stream_result {
-    uint64_t sync_candidates;   /* not filled by the GPU path (0)                 */
     uint64_t header_candidates; /* headers passing validity + CRC-8               */
     uint64_t frames;            /* resolved frames, any status                    */
     uint64_t frames_ok;
     uint64_t samples;           /* inter-channel samples in OK frames             */
-    uint64_t pcm_bytes;         /* end of the highest OK frame, bytes             */
+    uint64_t pcm_bytes;         /* end of the highest OK frame, bytes from out_offset (PLANAR: within a plane) */
+    uint64_t first_bad_frame;   /* index, among the stream's resolved frames in stream order, of the first one whose
+                                   status is not FLACGPU_FRAME_OK; UINT64_MAX when there is none.  The reference
+                                   reports which thing failed (flacmeta.go:756-788); this is the frame engine's
+                                   counterpart, and flacgpu_get_frames has the whole table. */
+    int32_t  first_error;       /* that frame's FLACGPU_FRAME_* status, 0 when there is none */
+    uint32_t md5_status;        /* FLACGPU_MD5_* (FLACGPU_FLAG_VERIFY_MD5)        */
 } flacgpu_stream_result;
 
 /* One resolved frame, as flacgpu_scan_frames reports it. */
@@ -272,6 +300,9 @@ typedef struct flacgpu_timing {
     uint32_t crc16_reread_spans;  /* candidate spans whose CRC-16 needed a second read of their bytes (the last
                                      span of every stream, and spans through 16 KiB of input with more than 31
                                      sync codes); every other span's CRC-16 comes out of the scan's single pass */
+    uint32_t launches;        /* kernels the call launched (streams are grouped by channel count and output
+                                 sample size: one skim and one set of decode launches per distinct shape) */
+    uint32_t shape_groups;    /* distinct (channels, output bytes per sample) shapes in the batch */
 } flacgpu_timing;
 
 /* Stream ordering (every entry point with a hip_stream argument).  hip_stream is a
@@ -297,23 +328,33 @@ int flacgpu_scan_frames(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
                         flacgpu_frame *frames, uint64_t cap, uint64_t *n_frames,
                         flacgpu_stream_result *results, void *hip_stream);
 
+/* The frame table of the handle's last flacgpu_scan_frames or decode call, in stream order: after a decode
+ * the statuses include what the subframe decoder found (FLACGPU_FRAME_BAD_SUBFRAME, _TRUNCATED, _LENGTH,
+ * _RANGE), so a caller who sees frames_ok < frames learns which frames failed and why.  frames: host array
+ * of cap entries (NULL with cap 0 just counts); FLACGPU_ERR_CAPACITY when cap is too small, with *n_frames
+ * set to the number needed. */
+int flacgpu_get_frames(flacgpu_handle *h, flacgpu_frame *frames, uint64_t cap, uint64_t *n_frames);
+
 /* Decode a device-resident batch: frame scan, Rice/LPC reconstruction,
  * decorrelation, and packing to interleaved signed little-endian samples of
- * ceil(bps/8) bytes (the byte string the STREAMINFO MD5 is defined over),
- * frame i of a stream written at first_sample * channels * bytes.  Frames
- * whose status is not OK leave their part of d_out unspecified.  Returns when
- * the work is complete. */
+ * ceil(bps/8) bytes (the byte string the STREAMINFO MD5 is defined over; other
+ * layouts: flacgpu_options.output_format), frame i of a stream written at
+ * (first_sample - sample_base) * channels * bytes.  Frames whose status is not
+ * OK leave their part of d_out unspecified.  Returns when the work is complete. */
 int flacgpu_decode_batch_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
                                 void *d_out, uint64_t out_bytes,
                                 const flacgpu_stream *streams, uint32_t n_streams,
                                 flacgpu_stream_result *results, void *hip_stream);
 
 /* The same decode for callers that cannot allocate device memory.  It has no counterpart in
- * the reference (which has no device at all): it exists for code under HIP graph capture,
- * tight serving loops and harnesses that forbid hipMalloc.  No handle: the workspace is a
- * static device array of about 3.5 MiB that every GPU the library runs on holds until the
+ * the reference (which has no device at all): it exists for tight serving loops and harnesses
+ * that forbid hipMalloc.  It is NOT capturable into a HIP graph: like the handle entry point it
+ * reads two counts back to the host in the middle (frame header candidates, per-stream ranges)
+ * and synchronises hip_stream for them and again for the results.  No handle: the workspace is
+ * a static device array of about 3.5 MiB that every GPU the library runs on holds until the
  * process ends, so the call allocates and frees nothing (its first call on a device looks
- * the array's address up and builds 1.3 KB of CRC tables in it).  Limits, checked, with
+ * the array's address up, builds 2.6 KB of CRC tables in it and synchronises).  Output is
+ * FLACGPU_OUT_PACKED, no timing, no MD5 check.  Limits, checked, with
  * FLACGPU_ERR_CAPACITY beyond them: in_bytes <= FLACGPU_NOALLOC_MAX_IN_BYTES, n_streams <=
  * FLACGPU_NOALLOC_MAX_STREAMS, and at most FLACGPU_NOALLOC_MAX_CANDIDATES frame header
  * candidates in the batch (frames plus false sync codes that pass CRC-8).  `device`: HIP
