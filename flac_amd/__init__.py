@@ -19,6 +19,11 @@ OK = 0
 FRAME_OK, FRAME_BAD_CRC16, FRAME_BAD_SUBFRAME, FRAME_TRUNCATED, FRAME_LENGTH, FRAME_RANGE, FRAME_UNSUPPORTED, \
     FRAME_SKIPPED = range(8)
 FLAG_TIMING = 1
+FLAG_VERIFY_MD5 = 2
+OUT_PACKED, OUT_S32, OUT_PLANAR = 0, 1, 2      # flacgpu_options.output_format
+MD5_NOT_CHECKED, MD5_MATCH, MD5_MISMATCH = 0, 1, 2
+API_VERSION = 2
+NO_BAD_FRAME = 0xFFFFFFFFFFFFFFFF
 ENC_MD5 = 1
 STEREO_EXACT = -1      # flacgpu_encode_options.stereo_mode: all four candidate channels planned, cheapest pair
 STEREO_ESTIMATE = -2   # the pair picked first from short predictors, its two channels planned
@@ -104,18 +109,19 @@ class CuesheetHead(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("flags", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32)]
+                ("output_format", ctypes.c_uint32)]
 
 
 class Stream(ctypes.Structure):
     _fields_ = [("in_offset", ctypes.c_uint64), ("in_length", ctypes.c_uint64), ("out_offset", ctypes.c_uint64),
-                ("out_capacity", ctypes.c_uint64), ("info", StreamInfo)]
+                ("out_capacity", ctypes.c_uint64), ("sample_base", ctypes.c_uint64), ("info", StreamInfo)]
 
 
 class StreamResult(ctypes.Structure):
-    _fields_ = [("sync_candidates", ctypes.c_uint64), ("header_candidates", ctypes.c_uint64),
+    _fields_ = [("header_candidates", ctypes.c_uint64),
                 ("frames", ctypes.c_uint64), ("frames_ok", ctypes.c_uint64), ("samples", ctypes.c_uint64),
-                ("pcm_bytes", ctypes.c_uint64)]
+                ("pcm_bytes", ctypes.c_uint64), ("first_bad_frame", ctypes.c_uint64), ("first_error", ctypes.c_int32),
+                ("md5_status", ctypes.c_uint32)]
 
 
 class Frame(ctypes.Structure):
@@ -130,7 +136,7 @@ class Timing(ctypes.Structure):
                 ("resolve_ms", ctypes.c_float), ("skim_ms", ctypes.c_float), ("decode_ms", ctypes.c_float),
                 ("results_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("candidates", ctypes.c_uint64),
                 ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64), ("decode_classes", ctypes.c_uint32),
-                ("crc16_reread_spans", ctypes.c_uint32)]
+                ("crc16_reread_spans", ctypes.c_uint32), ("launches", ctypes.c_uint32), ("shape_groups", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -181,6 +187,7 @@ EXPORTS = [
     "flacgpu_parse_vorbis_comment", "flacgpu_parse_picture", "flacgpu_picture_type_string", "flacgpu_parse_application",
     "flacgpu_parse_cuesheet", "flacgpu_skip_id3v2",
     "flacgpu_decode_batch_device_noalloc", "flacgpu_noalloc_last_error",
+    "flacgpu_get_frames", "flacgpu_api_version",
 ]
 
 _lib = None
@@ -234,6 +241,10 @@ def lib():
                                           ctypes.POINTER(u64), ctypes.POINTER(StreamResult), vp]
         L.flacgpu_decode_batch_device.argtypes = [vp, vp, u64, vp, u64, ctypes.POINTER(Stream), u32,
                                                   ctypes.POINTER(StreamResult), vp]
+        L.flacgpu_get_frames.argtypes = [vp, ctypes.POINTER(Frame), u64, ctypes.POINTER(u64)]
+        L.flacgpu_api_version.argtypes = []
+        if L.flacgpu_api_version() != API_VERSION:
+            raise ImportError(f"{LIB_PATH} has API version {L.flacgpu_api_version()}, this binding wants {API_VERSION}: rebuild it")
         L.flacgpu_decode_batch_device_noalloc.argtypes = [ctypes.c_int, vp, u64, vp, u64, ctypes.POINTER(Stream), u32,
                                                           ctypes.POINTER(StreamResult), vp]
         L.flacgpu_noalloc_last_error.restype = ctypes.c_char_p
@@ -400,9 +411,10 @@ def decode_batch_device_noalloc(device, d_in, in_bytes, d_out, out_bytes, stream
 class Decoder:
     """One handle = one GPU's workspace (flacgpu_create / flacgpu_destroy)."""
 
-    def __init__(self, device=0, timing=False):
+    def __init__(self, device=0, timing=False, output_format=OUT_PACKED, verify_md5=False):
         self._h = ctypes.c_void_p()
-        o = Options(ctypes.sizeof(Options), int(device), FLAG_TIMING if timing else 0, 0)
+        o = Options(ctypes.sizeof(Options), int(device), (FLAG_TIMING if timing else 0) | (FLAG_VERIFY_MD5 if verify_md5 else 0),
+                    int(output_format))
         rc = lib().flacgpu_create(ctypes.byref(o), ctypes.byref(self._h))
         if rc:
             raise FlacError(rc, "flacgpu_create")
@@ -425,13 +437,22 @@ class Decoder:
 
     @staticmethod
     def make_streams(entries):
-        """entries: iterable of (in_offset, in_length, out_offset, out_capacity, StreamInfo)."""
+        """entries: iterable of (in_offset, in_length, out_offset, out_capacity, StreamInfo[, sample_base])."""
         entries = list(entries)
         arr = (Stream * len(entries))()
-        for i, (io, il, oo, oc, si) in enumerate(entries):
-            arr[i].in_offset, arr[i].in_length, arr[i].out_offset, arr[i].out_capacity = io, il, oo, oc
-            ctypes.memmove(ctypes.byref(arr[i].info), ctypes.byref(si), ctypes.sizeof(StreamInfo))
+        for i, e in enumerate(entries):
+            arr[i].in_offset, arr[i].in_length, arr[i].out_offset, arr[i].out_capacity = e[:4]
+            arr[i].sample_base = e[5] if len(e) > 5 else 0
+            ctypes.memmove(ctypes.byref(arr[i].info), ctypes.byref(e[4]), ctypes.sizeof(StreamInfo))
         return arr
+
+    def get_frames(self):
+        """flacgpu_get_frames: the frame table of this handle's last scan or decode call (statuses as the decoder left them)."""
+        nf = ctypes.c_uint64()
+        self._check(lib().flacgpu_get_frames(self._h, None, 0, ctypes.byref(nf)))
+        frames = (Frame * max(1, nf.value))()
+        self._check(lib().flacgpu_get_frames(self._h, frames, nf.value, ctypes.byref(nf)))
+        return [frames[i] for i in range(nf.value)]
 
     def scan_frames(self, d_in, in_bytes, streams, hip_stream=0):
         n = len(streams)

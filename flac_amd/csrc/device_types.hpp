@@ -13,16 +13,19 @@ struct StreamDev {
     uint64_t out_off;        // bytes from d_out
     uint64_t out_cap;
     uint64_t total_samples;  // 0 = unknown
+    uint64_t sample_base;    // inter-channel index of the sample that lands at out_off (frame ranges of a long stream)
+    uint64_t plane_stride;   // planar output: bytes from one channel's plane to the next; 0 = interleaved
     uint32_t max_bs;         // STREAMINFO MaxBlockSize
     uint32_t cand_begin;     // [cand_begin, cand_end) in the candidate arrays
     uint32_t cand_end;
     uint32_t pending;        // some frame of this stream spans more than one candidate
     uint8_t  channels;
     uint8_t  bps;
-    uint8_t  bytes_ps;       // ceil(bps / 8)
+    uint8_t  bytes_ps;       // bytes per sample in the output: ceil(bps / 8), or 4 with 32-bit output
     uint8_t  pad;
     uint32_t pad2;
 };
+static_assert(sizeof(StreamDev) % 8 == 0, "StreamDev is copied as an array");
 
 // Per-stream reduction written by k_results.
 struct ResultDev {
@@ -31,6 +34,30 @@ struct ResultDev {
     uint64_t frames_ok;
     uint64_t samples;
     uint64_t pcm_bytes;
+    uint64_t first_bad_frame;   // index among the stream's frames (skipped candidates not counted); ~0 = none
+    int32_t  first_error;
+    uint32_t pad;
+};
+
+// Which candidates a skim or decode launch works on: item i of the launch is candidate base[j] + (i - start[j]) for the
+// segment j with start[j] <= i < start[j + 1].  Streams of one shape (channel count, output sample size) need
+// not be neighbours in the batch: their candidate ranges are the segments.  One segment needs no table.
+struct FrameMap {
+    const uint32_t *start;   // [nseg + 1] item index at which each segment starts; null = one segment
+    const uint32_t *base;    // [nseg] first candidate of each segment
+    uint32_t nseg;
+    uint32_t first;          // one segment: its first candidate
+    uint32_t count;          // items in all
+    __device__ inline uint32_t candidate(uint32_t i) const
+    {
+        if (!start) return first + i;
+        uint32_t lo = 0, hi = nseg;   // the last segment with start <= i
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (start[mid] <= i) lo = mid; else hi = mid;
+        }
+        return base[lo] + (i - start[lo]);
+    }
 };
 
 // Candidate info word: blocksize:16 | header_len:5 | ch_assign:4 | (bps-1):5 | variable:1

@@ -85,18 +85,33 @@ struct Roctx {
     }
 };
 
+const Roctx &roctx()
+{
+    static const Roctx r;
+    return r;
+}
+thread_local bool g_range_open = false;   // a stage range of this thread's current call is pushed and not yet popped
+
 // End of stage `which` on stream s: its timing event, and the range of the stage that follows.
 void mark(flacgpu_handle *h, int which, hipStream_t s)
 {
     if (h->flags & FLACGPU_FLAG_TIMING) (void)hipEventRecord(h->ev[which], s);
-    static const Roctx roctx;
-    if (roctx.push) {
+    const Roctx &rt = roctx();
+    if (rt.push) {
         static const char *const next_stage[EV_COUNT] = {"flacgpu:scan", "flacgpu:compact", "flacgpu:crc16", "flacgpu:resolve",
                                                          "flacgpu:skim", "flacgpu:decode", "flacgpu:results", nullptr};
-        if (which != EV_START) (void)roctx.pop();
-        if (next_stage[which]) (void)roctx.push(next_stage[which]);
+        if (g_range_open) { (void)rt.pop(); g_range_open = false; }
+        if (next_stage[which]) { (void)rt.push(next_stage[which]); g_range_open = true; }
     }
 }
+
+// Closes the stage range an error return left open (every entry point that calls mark() holds one of these).
+struct RangeGuard {
+    ~RangeGuard()
+    {
+        if (g_range_open) { (void)roctx().pop(); g_range_open = false; }
+    }
+};
 
 // Validates the batch description and builds the device stream table.
 int build_streams(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes, const flacgpu_stream *streams, uint32_t n,
@@ -111,6 +126,7 @@ int build_streams(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes, cons
         if (s.in_length >= (1ull << 31)) return fail(h, FLACGPU_ERR_UNSUPPORTED, "stream of 2 GiB or more");
         if (need_out && (s.out_offset > out_bytes || s.out_capacity > out_bytes - s.out_offset))
             return fail(h, FLACGPU_ERR_ARG, "stream exceeds the output buffer");
+        if (s.info.total_samples && s.sample_base > s.info.total_samples) return fail(h, FLACGPU_ERR_ARG, "sample_base beyond TotalSamples");
         if (s.info.channels < 1 || s.info.channels > 8 || s.info.bits_per_sample < 4 || s.info.bits_per_sample > 32 ||
             s.info.max_blocksize < 16)
             return fail(h, FLACGPU_ERR_STREAMINFO, "STREAMINFO out of bounds");
@@ -120,7 +136,11 @@ int build_streams(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes, cons
         d.in_off = s.in_offset; d.in_len = s.in_length; d.out_off = s.out_offset;
         d.out_cap = need_out ? s.out_capacity : ~0ull;
         d.total_samples = s.info.total_samples; d.max_bs = s.info.max_blocksize;
-        d.channels = s.info.channels; d.bps = s.info.bits_per_sample; d.bytes_ps = (uint8_t)((s.info.bits_per_sample + 7) / 8);
+        d.sample_base = s.sample_base;
+        d.channels = s.info.channels; d.bps = s.info.bits_per_sample;
+        d.bytes_ps = h->output_format == FLACGPU_OUT_S32 ? 4 : (uint8_t)((s.info.bits_per_sample + 7) / 8);
+        // planar: equal planes, each a whole number of dwords
+        if (need_out && h->output_format == FLACGPU_OUT_PLANAR) d.plane_stride = (s.out_capacity / s.info.channels) & ~(uint64_t)3;
         h->h_streams[i] = d;
     }
     return FLACGPU_OK;
@@ -186,6 +206,7 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
         k_resolve_walk<<<(n + 3) / 4, 256, 0, st>>>((const StreamDev *)h->streams.p, n, c);
     }
     mark(h, EV_RESOLVE, st);
+    h->launches = n_cand ? 10 : 4;   // scan, two prefix kernels, stream ranges; with candidates: compact, fill, two CRC-16, two resolve
     HIP_TRY(hipMemcpyAsync(h->h_streams.data(), h->streams.p, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost, st));
     h->n_reread = 0;
     if (n_cand) HIP_TRY(hipMemcpyAsync(&h->n_reread, (uint32_t *)h->counter.p + 1, 4, hipMemcpyDeviceToHost, st));
@@ -205,13 +226,65 @@ int fetch_results(flacgpu_handle *h, uint32_t n, flacgpu_stream_result *results,
     HIP_TRY(hipGetLastError());
     if (results)
         for (uint32_t i = 0; i < n; ++i) {
-            results[i].sync_candidates = 0;
             results[i].header_candidates = tmp[i].header_candidates;
             results[i].frames = tmp[i].frames;
             results[i].frames_ok = tmp[i].frames_ok;
             results[i].samples = tmp[i].samples;
             results[i].pcm_bytes = tmp[i].pcm_bytes;
+            results[i].first_bad_frame = tmp[i].first_bad_frame;
+            results[i].first_error = tmp[i].first_error;
+            results[i].md5_status = FLACGPU_MD5_NOT_CHECKED;
         }
+    ++h->launches;
+    return FLACGPU_OK;
+}
+
+// The frame table of the last scan or decode of this handle (candidate arrays still on the device), in stream order.
+int frame_table(flacgpu_handle *h, flacgpu_frame *frames, uint64_t cap, uint64_t *n_frames)
+{
+    const uint32_t nc = h->n_cand;
+    std::vector<uint64_t> goff(nc), num(nc);
+    std::vector<uint32_t> info(nc), stream(nc), len(nc);
+    std::vector<int32_t> status(nc);
+    if (nc) {
+        HIP_TRY(hipMemcpy(status.data(), h->status.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        if (frames) {
+            HIP_TRY(hipMemcpy(goff.data(), h->goff.p, (size_t)nc * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(num.data(), h->num.p, (size_t)nc * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(info.data(), h->info.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(stream.data(), h->stream.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(len.data(), h->len.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    uint64_t nf = 0;
+    int ret = FLACGPU_OK;
+    for (uint32_t r = 0; r < nc; ++r) {
+        if (status[r] == kFrameSkipped) continue;
+        if (frames) {
+            if (nf < cap) {
+                const StreamDev &s = h->h_streams[stream[r]];
+                flacgpu_frame f;
+                std::memset(&f, 0, sizeof f);
+                f.offset = goff[r] - s.in_off;
+                f.number = num[r];
+                f.variable = (uint8_t)info_var(info[r]);
+                f.first_sample = f.variable ? num[r] : num[r] * (uint64_t)s.max_bs;
+                f.length = len[r];
+                f.blocksize = info_bs(info[r]);
+                f.stream = stream[r];
+                f.status = status[r];
+                f.ch_assign = (uint8_t)info_ca(info[r]);
+                f.bps = (uint8_t)info_bps(info[r]);
+                f.header_len = (uint8_t)info_hl(info[r]);
+                frames[nf] = f;
+            } else {
+                ret = FLACGPU_ERR_CAPACITY;
+            }
+        }
+        ++nf;
+    }
+    *n_frames = nf;
+    if (ret) return fail(h, ret, "frame array too small");
     return FLACGPU_OK;
 }
 
@@ -220,6 +293,7 @@ void collect_timing(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes)
     flacgpu_timing t;
     std::memset(&t, 0, sizeof t);
     t.candidates = h->n_cand; t.in_bytes = in_bytes; t.out_bytes = out_bytes; t.crc16_reread_spans = h->n_reread;
+    t.launches = h->launches; t.shape_groups = h->shape_groups;
     if (h->flags & FLACGPU_FLAG_TIMING) {
         auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, h->ev[a], h->ev[b]); return ms; };
         t.scan_ms = el(EV_START, EV_SCAN);
@@ -270,7 +344,10 @@ int flacgpu_create(const flacgpu_options *opts, flacgpu_handle **out)
     if (!out) return FLACGPU_ERR_ARG;
     *out = nullptr;
     flacgpu_handle *h = new flacgpu_handle();
-    if (opts && opts->struct_size >= sizeof(flacgpu_options)) { h->device = opts->device; h->flags = opts->flags; }
+    if (opts && opts->struct_size >= sizeof(flacgpu_options)) {
+        h->device = opts->device; h->flags = opts->flags; h->output_format = opts->output_format;
+    }
+    if (h->output_format > FLACGPU_OUT_PLANAR) { delete h; return FLACGPU_ERR_ARG; }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || h->device < 0 || h->device >= count) { delete h; return FLACGPU_ERR_DEVICE; }
@@ -295,7 +372,7 @@ void flacgpu_destroy(flacgpu_handle *h)
     (void)hipSetDevice(h->device);
     DevBuf *all[] = {&h->streams, &h->results, &h->mask, &h->bitmap, &h->tile_count, &h->tile_base, &h->group_sum, &h->group_base,
                      &h->counter, &h->crc_tables, &h->segrec, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
-                     &h->seglen, &h->subpos, &h->next};
+                     &h->seglen, &h->subpos, &h->next, &h->shape_segs};
     for (DevBuf *b : all) release(*b);
     host_pipe_release(h);
     encode_release(h);
@@ -322,6 +399,7 @@ int flacgpu_scan_frames(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, 
     if ((uintptr_t)d_in & 15) return fail(h, FLACGPU_ERR_ARG, "d_in must be 16-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    RangeGuard guard;
     int rc = build_streams(h, in_bytes, 0, streams, n_streams, false);
     if (rc) return rc;
     if ((rc = run_scan(h, (const uint8_t *)d_in, in_bytes, n_streams, st))) return rc;
@@ -330,87 +408,90 @@ int flacgpu_scan_frames(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, 
     if ((rc = fetch_results(h, n_streams, results, st))) return rc;
     collect_timing(h, in_bytes, 0);
 
-    const uint32_t nc = h->n_cand;
-    std::vector<uint64_t> goff(nc), num(nc);
-    std::vector<uint32_t> info(nc), stream(nc), len(nc);
-    std::vector<int32_t> status(nc);
-    if (nc) {
-        HIP_TRY(hipMemcpy(goff.data(), h->goff.p, (size_t)nc * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(num.data(), h->num.p, (size_t)nc * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(info.data(), h->info.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(stream.data(), h->stream.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(len.data(), h->len.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(status.data(), h->status.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
-    }
-    uint64_t nf = 0;
-    int ret = FLACGPU_OK;
-    for (uint32_t r = 0; r < nc; ++r) {
-        if (status[r] == kFrameSkipped) continue;
-        if (frames) {
-            if (nf < cap) {
-                const StreamDev &s = h->h_streams[stream[r]];
-                flacgpu_frame f;
-                std::memset(&f, 0, sizeof f);
-                f.offset = goff[r] - s.in_off;
-                f.number = num[r];
-                f.variable = (uint8_t)info_var(info[r]);
-                f.first_sample = f.variable ? num[r] : num[r] * (uint64_t)s.max_bs;
-                f.length = len[r];
-                f.blocksize = info_bs(info[r]);
-                f.stream = stream[r];
-                f.status = status[r];
-                f.ch_assign = (uint8_t)info_ca(info[r]);
-                f.bps = (uint8_t)info_bps(info[r]);
-                f.header_len = (uint8_t)info_hl(info[r]);
-                frames[nf] = f;
-            } else {
-                ret = FLACGPU_ERR_CAPACITY;
-            }
-        }
-        ++nf;
-    }
-    *n_frames = nf;
-    return ret;
+    return frame_table(h, frames, cap, n_frames);
 }
+
+int flacgpu_get_frames(flacgpu_handle *h, flacgpu_frame *frames, uint64_t cap, uint64_t *n_frames)
+{
+    if (!h || !n_frames || (!frames && cap)) return fail(h, FLACGPU_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->h_streams.empty()) { *n_frames = 0; return FLACGPU_OK; }
+    return frame_table(h, frames, cap, n_frames);
+}
+
+int flacgpu_api_version(void) { return FLACGPU_API_VERSION; }
 
 // The body of both device-resident decode entry points; `st` is the stream everything runs on.
 static int decode_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes, void *d_out, uint64_t out_bytes,
                          const flacgpu_stream *streams, uint32_t n_streams, flacgpu_stream_result *results, hipStream_t st)
 {
+    RangeGuard guard;
     int rc = build_streams(h, in_bytes, out_bytes, streams, n_streams, true);
     if (rc) return rc;
     if ((rc = run_scan(h, (const uint8_t *)d_in, in_bytes, n_streams, st))) return rc;
 
-    // runs of consecutive streams with the same channel count and sample bytes share launches
-    struct Run { uint32_t r_begin, r_end, C, B; };
-    std::vector<Run> runs;
+    // Streams of one shape (channel count, output bytes per sample) share one skim launch and one set of decode
+    // launches, wherever they lie in the batch: a group's frames are the candidate ranges of its streams, joined
+    // where they touch.  A group of one range needs no table; the others get theirs in h->shape_segs.
+    struct Group { uint32_t C, B, count; std::vector<uint32_t> start, base; size_t table_off; };
+    std::vector<Group> groups;
     for (uint32_t i = 0; i < n_streams; ++i) {
         const StreamDev &s = h->h_streams[i];
         if (s.cand_end == s.cand_begin) continue;
-        if (!runs.empty() && runs.back().C == s.channels && runs.back().B == s.bytes_ps && runs.back().r_end == s.cand_begin)
-            runs.back().r_end = s.cand_end;
-        else
-            runs.push_back({s.cand_begin, s.cand_end, s.channels, s.bytes_ps});
+        Group *g = nullptr;
+        for (Group &x : groups)
+            if (x.C == s.channels && x.B == s.bytes_ps) { g = &x; break; }
+        if (!g) { groups.push_back(Group{s.channels, s.bytes_ps, 0, {}, {}, 0}); g = &groups.back(); }
+        const uint32_t n = s.cand_end - s.cand_begin;
+        if (!g->base.empty() && g->base.back() + (g->count - g->start.back()) == s.cand_begin) {
+            g->count += n;    // continues the group's last range
+        } else {
+            g->start.push_back(g->count);
+            g->base.push_back(s.cand_begin);
+            g->count += n;
+        }
     }
+    h->shape_groups = (uint32_t)groups.size();
+    h->h_shape_segs.clear();
+    for (Group &g : groups) {
+        if (g.base.size() < 2) continue;
+        g.table_off = h->h_shape_segs.size();
+        h->h_shape_segs.insert(h->h_shape_segs.end(), g.start.begin(), g.start.end());
+        h->h_shape_segs.push_back(g.count);
+        h->h_shape_segs.insert(h->h_shape_segs.end(), g.base.begin(), g.base.end());
+    }
+    if (!h->h_shape_segs.empty()) {
+        if ((rc = reserve(h, h->shape_segs, h->h_shape_segs.size() * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->shape_segs.p, h->h_shape_segs.data(), h->h_shape_segs.size() * 4, hipMemcpyHostToDevice, st));
+    }
+    auto frame_map = [&](const Group &g) {
+        FrameMap m;
+        m.start = nullptr; m.base = nullptr; m.nseg = 1; m.first = g.base[0]; m.count = g.count;
+        if (g.base.size() > 1) {
+            m.start = (const uint32_t *)h->shape_segs.p + g.table_off;
+            m.base = m.start + g.base.size() + 1;
+            m.nseg = (uint32_t)g.base.size();
+        }
+        return m;
+    };
     CandArrays c = cand_arrays(h);
     const uint64_t in_vecs = (in_bytes + 15) / 16;
     if (h->flags & FLACGPU_FLAG_TIMING) HIP_TRY(hipMemsetAsync((uint32_t *)h->counter.p + 12, 0, 4, st));
-    for (const Run &r : runs) {
-        const uint32_t nf = r.r_end - r.r_begin;
-        k_skim<<<(nf + 255) / 256, 256, 0, st>>>((const uint8_t *)d_in, in_vecs, c, r.r_begin, r.r_end, r.C,
-                                                 (const uint4 *)h->crc_tables.p);
+    for (const Group &g : groups) {
+        k_skim<<<(g.count + 255) / 256, 256, 0, st>>>((const uint8_t *)d_in, in_vecs, c, frame_map(g), g.C, (const uint4 *)h->crc_tables.p);
+        ++h->launches;
     }
     mark(h, EV_SKIM, st);
-    for (const Run &r : runs) {
-        const uint32_t nf = r.r_end - r.r_begin;
+    const bool planar = h->output_format == FLACGPU_OUT_PLANAR;
+    for (const Group &r : groups) {
         const uint32_t F = 64 / r.C;
-        const uint32_t waves = (nf + F - 1) / F;
+        const uint32_t waves = (r.count + F - 1) / F;
         const uint32_t blocks = (waves + 3) / 4;
         DecodeParams p;
         p.in = (const uint8_t *)d_in; p.in_vecs = in_vecs; p.out = (uint8_t *)d_out;
         p.spare = (const uint4 *)h->crc_tables.p;
         p.streams = (const StreamDev *)h->streams.p; p.c = c;
-        p.r_begin = r.r_begin; p.r_end = r.r_end; p.C = r.C; p.B = r.B;
+        p.map = frame_map(r); p.C = r.C; p.B = r.B;
         p.class_flags = (uint32_t *)h->counter.p + 4;
         p.check_flag = 0;
         HIP_TRY(hipMemsetAsync(p.class_flags, 0, 8 * sizeof(uint32_t), st));
@@ -418,7 +499,13 @@ static int decode_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
 #define FLACGPU_LAUNCH(MO, W, S) \
         k_decode<MO, W, S><<<blocks, 256, 4 * decode_wave_lds(r.C), st>>>(p); p.check_flag = 1
         // the first launch classifies every wave, so it is the class most waves of such streams fall in
-        if (r.C == 2 && r.B == 2) {
+        if (planar && r.B <= 2) {
+            FLACGPU_LAUNCH(12, 3, 4); FLACGPU_LAUNCH(32, 3, 4); FLACGPU_LAUNCH(12, 0, 4); FLACGPU_LAUNCH(32, 0, 4);
+            FLACGPU_LAUNCH(12, 1, 4); FLACGPU_LAUNCH(32, 1, 4); FLACGPU_LAUNCH(12, 2, 4); FLACGPU_LAUNCH(32, 2, 4);
+        } else if (planar) {
+            FLACGPU_LAUNCH(12, 0, 4); FLACGPU_LAUNCH(32, 0, 4); FLACGPU_LAUNCH(12, 1, 4); FLACGPU_LAUNCH(32, 1, 4);
+            FLACGPU_LAUNCH(12, 2, 4); FLACGPU_LAUNCH(32, 2, 4); FLACGPU_LAUNCH(12, 3, 4); FLACGPU_LAUNCH(32, 3, 4);
+        } else if (r.C == 2 && r.B == 2) {
             FLACGPU_LAUNCH(12, 3, 1); FLACGPU_LAUNCH(32, 3, 1); FLACGPU_LAUNCH(12, 0, 1); FLACGPU_LAUNCH(32, 0, 1);
             FLACGPU_LAUNCH(12, 1, 1); FLACGPU_LAUNCH(32, 1, 1); FLACGPU_LAUNCH(12, 2, 1); FLACGPU_LAUNCH(32, 2, 1);
         } else if (r.C == 1 && r.B == 2) {
@@ -438,7 +525,8 @@ static int decode_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
             FLACGPU_LAUNCH(12, 2, 0); FLACGPU_LAUNCH(32, 2, 0); FLACGPU_LAUNCH(12, 3, 0); FLACGPU_LAUNCH(32, 3, 0);
         }
 #undef FLACGPU_LAUNCH
-        if (h->flags & FLACGPU_FLAG_TIMING) k_or_class_flags<<<1, 64, 0, st>>>(p.class_flags, (uint32_t *)h->counter.p + 12);
+        h->launches += 8;
+        if (h->flags & FLACGPU_FLAG_TIMING) { k_or_class_flags<<<1, 64, 0, st>>>(p.class_flags, (uint32_t *)h->counter.p + 12); ++h->launches; }
     }
     mark(h, EV_DECODE, st);
     uint32_t classes = 0;
@@ -447,6 +535,28 @@ static int decode_device(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
     if ((rc = fetch_results(h, n_streams, results, st))) return rc;
     collect_timing(h, in_bytes, out_bytes);
     h->timing.decode_classes = classes;
+
+    // MD5 check: every stream the flag applies to is hashed where it lies, one lane per stream
+    if ((h->flags & FLACGPU_FLAG_VERIFY_MD5) && results && h->output_format == FLACGPU_OUT_PACKED) {
+        std::vector<uint64_t> offs, lens;
+        std::vector<uint32_t> which;
+        static const uint8_t zeros[16] = {};
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            const flacgpu_stream &s = streams[i];
+            const uint64_t want = s.info.total_samples * s.info.channels * ((s.info.bits_per_sample + 7) / 8);
+            if (!s.info.total_samples || s.sample_base || !std::memcmp(s.info.md5, zeros, 16)) continue;
+            if (results[i].frames_ok != results[i].frames || results[i].samples != s.info.total_samples || want > s.out_capacity) continue;
+            which.push_back(i); offs.push_back(s.out_offset); lens.push_back(want);
+        }
+        if (!which.empty()) {
+            h->h_md5.resize(which.size() * 16);
+            rc = flacgpu_md5_batch_device(h, d_out, out_bytes, offs.data(), lens.data(), (uint32_t)which.size(), h->h_md5.data(), st);
+            if (rc) return rc;
+            for (size_t j = 0; j < which.size(); ++j)
+                results[which[j]].md5_status = std::memcmp(&h->h_md5[j * 16], streams[which[j]].info.md5, 16) ? FLACGPU_MD5_MISMATCH
+                                                                                                            : FLACGPU_MD5_MATCH;
+        }
+    }
     return FLACGPU_OK;
 }
 
@@ -490,6 +600,7 @@ constexpr size_t kNaSizes[] = {
     na_round(kNaMaxCand * 8), na_round(kNaMaxCand * 8), na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 4),   // goff num info stream
     na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 2), na_round(kNaMaxCand * 4),   // len status segcrc seglen
     na_round(kNaMaxCand * 8 * 4), na_round(kNaMaxCand * 4),                                                  // subpos next
+    na_round((2 * kNaMaxStreams + 64) * 4),                                                                  // shape_segs
 };
 constexpr size_t na_total()
 {
@@ -530,7 +641,7 @@ int noalloc_setup(NoAllocState &s, int device, hipStream_t st)
     s.ptr = ptr;
     DevBuf *bufs[] = {&h->streams, &h->results, &h->mask, &h->bitmap, &h->tile_count, &h->tile_base, &h->group_sum, &h->group_base,
                       &h->counter, &h->crc_tables, &h->segrec, &h->goff, &h->num, &h->info, &h->stream, &h->len, &h->status, &h->segcrc,
-                      &h->seglen, &h->subpos, &h->next};
+                      &h->seglen, &h->subpos, &h->next, &h->shape_segs};
     static_assert(sizeof bufs / sizeof bufs[0] == sizeof kNaSizes / sizeof kNaSizes[0], "one size per buffer");
     size_t off = 0;
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; ++i) {
@@ -541,6 +652,7 @@ int noalloc_setup(NoAllocState &s, int device, hipStream_t st)
     h->cand_cap = (uint32_t)kNaMaxCand;
     h->h_streams.reserve(kNaMaxStreams);
     h->h_results.reserve(kNaMaxStreams);
+    h->h_shape_segs.reserve(2 * kNaMaxStreams + 64);
     k_crc16_build_tables<<<1, 256, 0, st>>>((uint16_t *)h->crc_tables.p);
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -554,13 +666,17 @@ int flacgpu_decode_batch_device_noalloc(int device, const void *d_in, uint64_t i
                                         const flacgpu_stream *streams, uint32_t n_streams, flacgpu_stream_result *results,
                                         void *hip_stream)
 {
-    if (device < 0 || device >= kNaMaxDevices) { g_na_error = "device ordinal out of range"; return FLACGPU_ERR_DEVICE; }
+    // A call that is refused for its arguments must not touch the state a running call on the same GPU is using
+    // (its error text included): these refusals go to a string of the calling thread.
+    g_na_error.clear();
+    auto refuse = [](int code, const char *msg) { g_na_error = msg; return code; };
+    if (device < 0 || device >= kNaMaxDevices) return refuse(FLACGPU_ERR_DEVICE, "device ordinal out of range");
+    if (!d_in || !d_out || !streams || !n_streams) return refuse(FLACGPU_ERR_ARG, "null argument");
+    if ((uintptr_t)d_in & 15) return refuse(FLACGPU_ERR_ARG, "d_in must be 16-byte aligned");
+    if (in_bytes > kNaMaxIn) return refuse(FLACGPU_ERR_CAPACITY, "in_bytes exceeds FLACGPU_NOALLOC_MAX_IN_BYTES");
+    if (n_streams > kNaMaxStreams) return refuse(FLACGPU_ERR_CAPACITY, "n_streams exceeds FLACGPU_NOALLOC_MAX_STREAMS");
     NoAllocState &s = g_na[device];
     flacgpu_handle *h = &s.h;
-    if (!d_in || !d_out || !streams || !n_streams) return fail(h, FLACGPU_ERR_ARG, "null argument");
-    if ((uintptr_t)d_in & 15) return fail(h, FLACGPU_ERR_ARG, "d_in must be 16-byte aligned");
-    if (in_bytes > kNaMaxIn) return fail(h, FLACGPU_ERR_CAPACITY, "in_bytes exceeds FLACGPU_NOALLOC_MAX_IN_BYTES");
-    if (n_streams > kNaMaxStreams) return fail(h, FLACGPU_ERR_CAPACITY, "n_streams exceeds FLACGPU_NOALLOC_MAX_STREAMS");
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;   // NULL: the legacy default stream
     {
@@ -575,7 +691,7 @@ int flacgpu_decode_batch_device_noalloc(int device, const void *d_in, uint64_t i
 
 const char *flacgpu_noalloc_last_error(int device)
 {
-    if (device < 0 || device >= kNaMaxDevices) return g_na_error.c_str();
+    if (!g_na_error.empty() || device < 0 || device >= kNaMaxDevices) return g_na_error.c_str();   // this thread's last call was refused for its arguments
     return g_na[device].h.err.c_str();
 }
 
@@ -599,6 +715,7 @@ int flacgpu_decode_batch(flacgpu_handle *h, const uint8_t *const *bufs, const ui
             flacgpu_stream &s = streams[k];
             s.in_offset = items[first + k].in_off; s.in_length = lens[first + k];
             s.out_offset = items[first + k].out_off; s.out_capacity = out_caps[first + k];
+            s.sample_base = 0;
             s.info = infos[first + k];
         }
         const int rc = decode_device(h, d_in, std::max<uint64_t>(in_bytes, 16), d_out, out_bytes, streams.data(), (uint32_t)count,
@@ -607,7 +724,8 @@ int flacgpu_decode_batch(flacgpu_handle *h, const uint8_t *const *bufs, const ui
         sum.scan_ms += t.scan_ms; sum.compact_ms += t.compact_ms; sum.crc16_ms += t.crc16_ms; sum.resolve_ms += t.resolve_ms;
         sum.skim_ms += t.skim_ms; sum.decode_ms += t.decode_ms; sum.results_ms += t.results_ms; sum.total_ms += t.total_ms;
         sum.candidates += t.candidates; sum.in_bytes += t.in_bytes; sum.out_bytes += t.out_bytes; sum.decode_classes |= t.decode_classes;
-        sum.crc16_reread_spans += t.crc16_reread_spans;
+        sum.crc16_reread_spans += t.crc16_reread_spans; sum.launches += t.launches;
+        sum.shape_groups = std::max(sum.shape_groups, t.shape_groups);
         return rc;
     };
     const int rc = run_staged(h, *host_pipe(h), items, h->own_stream, true, compute, [&](size_t i) { return out_caps[i]; });

@@ -828,7 +828,9 @@ __device__ inline int range_status(const StreamDev &s, uint32_t info, uint64_t n
     const uint64_t first = info_var(info) ? num : num * (uint64_t)s.max_bs;
     const uint64_t end = first + info_bs(info);
     if (s.total_samples && end > s.total_samples) return kFrameRange;
-    if (end * s.channels * s.bytes_ps > s.out_cap) return kFrameRange;
+    if (first < s.sample_base) return kFrameRange;
+    const uint64_t rel = end - s.sample_base;   // samples from the start of the stream's output region
+    if (s.plane_stride ? rel * s.bytes_ps > s.plane_stride : rel * s.channels * s.bytes_ps > s.out_cap) return kFrameRange;
     return kFrameOK;
 }
 
@@ -897,6 +899,7 @@ __global__ __launch_bounds__(256) void k_results(const StreamDev *__restrict__ s
     if (s >= n_streams) return;
     const StreamDev st = streams[s];
     uint64_t frames = 0, ok = 0, samples = 0, end = 0;
+    uint32_t bad = 0xFFFFFFFFu;   // first candidate of this lane that is a frame with an error
     for (uint32_t r = st.cand_begin + lane; r < st.cand_end; r += 64) {
         const int status = c.status[r];
         if (status == kFrameSkipped) continue;
@@ -906,8 +909,10 @@ __global__ __launch_bounds__(256) void k_results(const StreamDev *__restrict__ s
             const uint64_t first = info_var(info) ? c.num[r] : c.num[r] * (uint64_t)st.max_bs;
             ++ok;
             samples += info_bs(info);
-            const uint64_t e = (first + info_bs(info)) * st.channels * st.bytes_ps;
+            const uint64_t e = (first - st.sample_base + info_bs(info)) * (st.plane_stride ? 1u : st.channels) * st.bytes_ps;
             end = e > end ? e : end;
+        } else if (bad == 0xFFFFFFFFu) {
+            bad = r;
         }
     }
 #pragma unroll
@@ -917,11 +922,24 @@ __global__ __launch_bounds__(256) void k_results(const StreamDev *__restrict__ s
         samples += __shfl_xor(samples, d);
         const uint64_t o = __shfl_xor(end, d);
         end = o > end ? o : end;
+        bad = min(bad, (uint32_t)__shfl_xor((int)bad, d));
+    }
+    // the first bad frame's index counts the frames in front of it, not the candidates
+    uint64_t before = 0;
+    int32_t bad_status = 0;
+    if (bad != 0xFFFFFFFFu) {
+        for (uint32_t r = st.cand_begin + lane; r < bad; r += 64) before += c.status[r] != kFrameSkipped ? 1u : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+        bad_status = c.status[bad];
     }
     if (lane == 0) {
         ResultDev res;
         res.header_candidates = st.cand_end - st.cand_begin;
         res.frames = frames; res.frames_ok = ok; res.samples = samples; res.pcm_bytes = end;
+        res.first_bad_frame = bad != 0xFFFFFFFFu ? before : ~0ull;
+        res.first_error = bad_status;
+        res.pad = 0;
         out[s] = res;
     }
 }

@@ -33,7 +33,13 @@ struct flacgpu_handle {
     // decode
     flacgpu::DevBuf streams, results, mask, bitmap, tile_count, tile_base, group_sum, group_base, counter, crc_tables, segrec;
     flacgpu::DevBuf goff, num, info, stream, len, status, segcrc, seglen, subpos, next;
+    flacgpu::DevBuf shape_segs;   // FrameMap tables of the shape groups: per group its starts, then its bases
+    std::vector<uint32_t> h_shape_segs;
     uint32_t cand_cap = 0;
+    uint32_t output_format = 0;   // FLACGPU_OUT_*
+    uint32_t launches = 0;        // kernels launched by the current call
+    uint32_t shape_groups = 0;
+    std::vector<uint8_t> h_md5;   // digests of the MD5 check
     hipEvent_t ev[flacgpu::EV_COUNT] = {};
     flacgpu_timing timing = {};
     std::vector<flacgpu::StreamDev> h_streams;

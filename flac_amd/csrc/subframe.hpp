@@ -370,7 +370,7 @@ __device__ inline uint32_t wave_max_u32(uint32_t v)
 
 // -------------------------------------------------------------------- skim --
 
-// One lane per candidate frame r in [r_begin, r_end); C channels.  Records
+// One lane per candidate frame of `map` (the frames of all streams with C channels).  Records
 // subpos[r*8 + c] for every channel and turns frames that fail to parse into
 // their error status.  Subframes 0 .. C-2 are walked one after the other; the
 // last one is checked by its decode lane.
@@ -383,15 +383,16 @@ __device__ inline uint32_t wave_max_u32(uint32_t v)
 // parameters are small: a lane whose codes did not fit (or whose ring ran dry)
 // is rolled back and walks the group code by code.
 __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, uint64_t in_vecs, CandArrays c,
-                                              uint32_t r_begin, uint32_t r_end, uint32_t C, const uint4 *spare)
+                                              FrameMap map, uint32_t C, const uint4 *spare)
 {
     constexpr uint32_t kSlots = kRingSlots + 1;   // a second mirror slot: the wide-window loop reads three consecutive words
     __shared__ __align__(16) uint32_t s_ring[4 * kSlots * 64];
     constexpr uint32_t G = 16;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *wave_ring = s_ring + (threadIdx.x >> 6) * (kSlots * 64);
-    const uint32_t r = r_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = r < r_end;
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = item < map.count;
+    const uint32_t r = active ? map.candidate(item) : 0u;
     if (active) active = c.status[r] == kFrameOK;
     BitReader br;
     br.null(wave_ring + lane, spare);
@@ -567,8 +568,8 @@ struct DecodeParams {
     const StreamDev *streams;
     const uint4 *spare;    // 32 readable bytes of device memory (see BitReader::init)
     CandArrays c;
-    uint32_t r_begin, r_end;
-    uint32_t C;            // channels of every frame in [r_begin, r_end)
+    FrameMap map;          // the frames of the launch: all streams of one shape
+    uint32_t C;            // channels of every frame of the launch
     uint32_t B;            // bytes per sample in the output
     uint32_t *class_flags; // [8]: set when some wave of the run belongs to that (taps, arithmetic) class
     uint32_t check_flag;   // leave at once when this instantiation's flag is not set
@@ -612,7 +613,8 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 // LAYOUT: 0 = any channel count and sample size whose rows are shorter than a line (C * B < 8: the general
 //         write-out in four-slot items); 1 = C == 2 and B == 2 (STEREO16), the write-out specialised for it;
 //         2 = C == 1 and B == 2 in the 16-bit pair class (MONO16); 3 = C * B >= 8 (WIDE: the general write-out in
-//         sixteen-slot items, tile rows 65 words apart).
+//         sixteen-slot items, tile rows 65 words apart); 4 = planar output: every channel of a stream has a plane of
+//         its own (StreamDev::plane_stride apart), a lane's samples go to its channel's plane, four per store.
 // Lanes stage their samples as coded; stereo decorrelation and packing to the output's sample size happen
 // in the write-out, once per output word.
 //
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     // seconds of wave time apart, cost the memory system a quarter of the kernel's time).  The unrolled body of
     // that class only keeps samples that fit 16 bits; the few that do not (generic body, 17-bit side channels)
     // are marked in `widemask`, one bit per tile column, and send the write-out down its slow path.
-    constexpr bool STEREO16 = LAYOUT == 1, MONO16 = LAYOUT == 2, WIDE = LAYOUT == 3;
+    constexpr bool STEREO16 = LAYOUT == 1, MONO16 = LAYOUT == 2, WIDE = LAYOUT == 3, PLANAR = LAYOUT == 4;
     // words per sample column of the raw tile.  WIDE: a lane of the write-out reads channel j of column g (+ 8) of
     // frame f, word 65 * column + C * f + j; with C = 8 the 32 lanes of a half wave (f = 0..3, g = 0..7) then
     // fall into 32 different banks (with 66 words they shared 8)
@@ -659,8 +661,9 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
 
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const uint32_t fl = lane / C, ch = lane - fl * C;
-    const uint32_t r = p.r_begin + wave * F + fl;
-    bool active = fl < F && r < p.r_end;
+    const uint32_t item = wave * F + fl;
+    bool active = fl < F && item < p.map.count;
+    const uint32_t r = active ? p.map.candidate(item) : 0u;
     int status = kFrameOK;
     if (active) status = p.c.status[r];
     active = active && status == kFrameOK;
@@ -680,7 +683,8 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
         br.init(p.in, p.in_vecs, goff, wave_ring + lane, p.spare);
         br.seek(p.c.subpos[(uint64_t)r * 8 + ch]);
         const uint64_t first = info_var(info) ? p.c.num[r] : p.c.num[r] * (uint64_t)s.max_bs;
-        dst = s.out_off + first * CB;   // from p.out
+        // from p.out (the range check has seen to first >= sample_base); planar: this lane's own plane
+        dst = PLANAR ? s.out_off + ch * s.plane_stride + (first - s.sample_base) * B : s.out_off + (first - s.sample_base) * CB;
         const int rc = read_subframe_header(br, info_bps(info) + (is_side(ca, ch) ? 1 : 0), bs, limit, h);
         if (rc) { status = rc; h.kind = 0; h.order = 0; }
     }
@@ -781,6 +785,22 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             dc_lmul2[it] = (uint32_t)dc_lmul[it] * 0x10001u;
             dc_rmul2[it] = ((uint32_t)dc_rmul[it] & 0xFFFFu) * 0x10001u;
             row16[it] = dwords && ((reinterpret_cast<uint64_t>(p.out) + fdst[it]) & 15) == 0;
+        }
+    } else if (PLANAR) {
+        // an item is four consecutive samples of one lane (= one channel of one frame): item = 64 * it + lane covers
+        // source lane 16 * it + (lane >> 2), samples 4 * (lane & 3) .. + 3, so four neighbours write one lane's 16 samples
+        const uint32_t tile_lds = (uint32_t)(uintptr_t)(lds_word *)tile_raw;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t src = it * 16 + (lane >> 2), quad = lane & 3, f = (src * inv_c) >> 16;
+            const bool ok = f < F;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q_src[it * 4 + j] = tile_lds + ((4 * quad + j) * RS + src) * 4;
+            const uint64_t dst_l = (uint64_t)__shfl((unsigned long long)dst, (int)src);
+            const uint32_t meta = frame_meta(ok ? f : 0u);
+            q_dst[it] = ok ? dst_l + quad * 4 * B : 0;
+            // block size | last sample column of the item (20-23) | channel assignment (24-27) | second channel of a pair (28)
+            q_meta[it] = ok ? (meta & 0xFFFFFu) | ((4 * quad + 3) << 20) | (((meta >> 20) & 15u) << 24) | ((src & 1u) << 28) : 0u;
         }
     } else {
         const uint32_t tile_lds = (uint32_t)(uintptr_t)(lds_word *)tile_raw;
@@ -1142,6 +1162,59 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 }
             }
             widemask = widemask_rest;
+        } else if (PLANAR) {
+            auto pack = [&](const uint32_t (&v)[4], uint32_t &d0, uint32_t &d1, uint32_t &d2) {
+                d0 = (v[0] & 0xFFFFFFu) | (v[1] << 24);
+                d1 = ((v[1] >> 8) & 0xFFFFu) | (v[2] << 16);
+                d2 = ((v[2] >> 16) & 0xFFu) | (v[3] << 8);
+            };
+            // the pair's other channel sits one word beside this one in the tile
+            auto channel_value = [&](uint32_t mine, uint32_t other, uint32_t m, bool second) {
+                uint32_t L, R;
+                decorrelate(m, second ? other : mine, second ? mine : other, L, R);
+                return second ? R : L;
+            };
+            bool ragged = false;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const uint32_t fbs_f = q_meta[it] & 0xFFFFFu;
+                if (t0 >= fbs_f) continue;
+                if (!dwords || ((q_meta[it] >> 20) & 15u) >= fbs_f - t0) { ragged = true; continue; }
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = *(lds_word *)(uintptr_t)q_src[it * 4 + j];
+                if (C == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = channel_value(v[j], *(lds_word *)(uintptr_t)(q_src[it * 4 + j] ^ 4u), (q_meta[it] >> 24) & 15u, (q_meta[it] >> 28) != 0);
+                }
+                uint8_t *q = p.out + q_dst[it] + (uint64_t)t0 * B;
+                if (B == 1) *reinterpret_cast<uint32_t *>(q) = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
+                else if (B == 2) *reinterpret_cast<Dwords2 *>(q) = Dwords2{(v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16)};
+                else if (B == 3) { uint32_t d0, d1, d2; pack(v, d0, d1, d2); *reinterpret_cast<Dwords3 *>(q) = Dwords3{d0, d1, d2}; }
+                else *reinterpret_cast<Dwords4 *>(q) = Dwords4{v[0], v[1], v[2], v[3]};
+            }
+            if (__any(ragged))
+#pragma unroll 1
+            for (uint32_t it = 0; it < 4; ++it) {
+                const uint32_t src = it * 16 + (lane >> 2), quad = lane & 3, f = (src * inv_c) >> 16;
+                const uint64_t dst_l = (uint64_t)__shfl((unsigned long long)dst, (int)src);   // lane reads: before the lanes part ways
+                const uint32_t meta = frame_meta(f < F ? f : 0u);
+                if (f >= F) continue;
+                const uint32_t fbs_f = meta & 0xFFFFFu;
+                if (t0 >= fbs_f) continue;
+                const uint32_t ncols = min(kTile, fbs_f - t0);
+                if (dwords && 4 * quad + 3 < ncols) continue;   // written above
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t col = 4 * quad + j;
+                    if (col >= ncols) continue;
+                    uint32_t x = tile_raw[col * RS + src];
+                    if (C == 2) x = channel_value(x, tile_raw[col * RS + (src ^ 1u)], (meta >> 20) & 15u, (src & 1u) != 0);
+                    uint8_t *at = p.out + dst_l + (uint64_t)(t0 + col) * B;
+                    for (uint32_t y = 0; y < B; ++y) at[y] = (uint8_t)(x >> (8 * y));
+                }
+            }
         } else {
             // four 24-bit samples as three dwords
             auto pack = [&](const uint32_t (&v)[4], uint32_t &d0, uint32_t &d1, uint32_t &d2) {

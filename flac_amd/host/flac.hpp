@@ -307,7 +307,18 @@ struct Metadata {
 // Result of decoding one stream (flacgpu_stream_result).
 struct StreamResult {
     uint64_t HeaderCandidates = 0, Frames = 0, FramesOK = 0, Samples = 0, PCMBytes = 0;
+    uint64_t FirstBadFrame = ~0ull;   // index of the first frame that did not decode, ~0 when every frame did
+    int32_t FirstError = 0;           // its FLACGPU_FRAME_* status
+    uint32_t MD5Status = FLACGPU_MD5_NOT_CHECKED;   // PCM against StreaminfoBlock.MD5Signature (flacmeta.go:664)
 };
+
+// Name of a per-frame status, for error texts in the reference's style (it names what failed, flacmeta.go:756-788).
+inline const char *FrameStatusString(int32_t status)
+{
+    static const char *const names[] = {"ok", "CRC-16 mismatch", "invalid subframe", "frame truncated", "frame length mismatch",
+                                        "samples outside the stream or the output", "unsupported", "inside another frame"};
+    return status >= 0 && status < 8 ? names[status] : "unknown";
+}
 
 // One GPU's frame engine (flacgpu_create / flacgpu_destroy).
 class Decoder {
@@ -317,10 +328,12 @@ public:
     Decoder &operator=(const Decoder &) = delete;
     ~Decoder() { Close(); }
     // NewDecoder: returns "" or the error text
-    std::string Open(int device)
+    std::string Open(int device, bool verifyMD5 = true)
     {
+        if (flacgpu_api_version() != FLACGPU_API_VERSION) return "libflacgpu was built from another version of flacgpu.h";
         flacgpu_options o;
-        o.struct_size = sizeof o; o.device = device; o.flags = 0; o.reserved = 0;
+        o.struct_size = sizeof o; o.device = device; o.flags = verifyMD5 ? FLACGPU_FLAG_VERIFY_MD5 : 0;
+        o.output_format = FLACGPU_OUT_PACKED;
         if (int rc = flacgpu_create(&o, &h_)) return std::string("flacgpu_create: ") + flacgpu_status_string(rc);
         return "";
     }
@@ -357,7 +370,11 @@ public:
             return std::string("decode: ") + flacgpu_status_string(rc) + ": " + flacgpu_last_error(h_);
         res.HeaderCandidates = r.header_candidates; res.Frames = r.frames; res.FramesOK = r.frames_ok;
         res.Samples = r.samples; res.PCMBytes = r.pcm_bytes;
+        res.FirstBadFrame = r.first_bad_frame; res.FirstError = r.first_error; res.MD5Status = r.md5_status;
         if (r.frames && !r.frames_ok) return "decode: no frame of the stream decoded";
+        if (r.frames_ok < r.frames)    // PCM of the other frames is in place; the caller decides whether that is an error
+            return std::string("decode: frame ") + std::to_string(r.first_bad_frame) + ": " + FrameStatusString(r.first_error);
+        if (r.md5_status == FLACGPU_MD5_MISMATCH) return "decode: PCM does not match the STREAMINFO MD5 signature";
         return "";
     }
 

@@ -1,10 +1,16 @@
-"""File-level sharding of a batch over the GPUs of one node.
+"""Sharding of the decode path over the GPUs of one node: by file, and by frame range of one long stream.
 
 FLAC files are independent and every frame is self-contained, so the decode path has no exchange
 step: rank r of W takes files r, r+W, r+2W, ... (round robin keeps shards balanced when file sizes
 drift along the list), decodes them on its own GPU with its own handle, and only the small per-file
 result rows travel afterwards.  One process per GPU, torch.distributed for the rows (RCCL on GPUs,
 gloo on CPU); nothing on the data path is a collective.
+
+A single long stream is cut at seek points instead (range_shards_with_samples): rank r decodes the r-th
+frame range into an output region of its own (flacgpu_stream.sample_base = the range's first sample).
+The one thing that cannot be done per range is the stream's MD5, a chain over all its bytes in order:
+chained_md5 moves the ranges' PCM to rank 0 (point-to-point, rank order = stream order) and finishes the
+digest there.
 """
 import numpy as np
 
@@ -43,7 +49,7 @@ def result_rows(indices, results, digests=None) -> np.ndarray:
     a 128-bit digest of its PCM split in two words (e.g. the MD5 the caller computed)."""
     rows = np.zeros((len(indices), len(ROW_FIELDS)), dtype=np.int64)
     for j, (i, r) in enumerate(zip(indices, results)):
-        rows[j, :5] = (i, r.frames, r.frames_ok, r.samples, getattr(r, "first_error", 0))
+        rows[j, :5] = (i, r.frames, r.frames_ok, r.samples, r.first_error)
         if digests is not None:
             d = digests[j]
             rows[j, 5] = int.from_bytes(d[:8], "little", signed=True)
@@ -80,3 +86,53 @@ def gather_rows(rows: np.ndarray, n_items: int, device=None):
     if not seen.all():
         raise RuntimeError(f"{int((~seen).sum())} streams were decoded by no rank")
     return table
+
+
+def range_shards_with_samples(seekpoints, audio_len: int, total_samples: int, parts: int):
+    """range_shards plus what a rank needs to decode its range into a region of its own:
+    [(offset, length, sample_base, n_samples)], n_samples = inter-channel samples the range holds (from the seek
+    points' SampleNumber, flacmeta.go:256-260; the last range ends at total_samples)."""
+    first_sample = {int(p.offset): int(p.sample_number) for p in seekpoints
+                    if int(p.sample_number) != 0xFFFFFFFFFFFFFFFF}
+    first_sample[0] = 0
+    shards = range_shards(seekpoints, audio_len, parts)
+    bases = [first_sample[o] for o, _ in shards] + [int(total_samples)]
+    return [(o, n, bases[i], bases[i + 1] - bases[i]) for i, (o, n) in enumerate(shards)]
+
+
+def my_range(shards, rank: int, world: int):
+    """The range rank `rank` decodes, or None when the seek table gave fewer ranges than ranks."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"rank {rank} of {world}")
+    return shards[rank] if rank < len(shards) else None
+
+
+def chained_md5(local_pcm, chunk_bytes: int = 64 << 20):
+    """MD5 of a stream whose PCM lies in rank order across the ranks (each rank passes its range's PCM as a
+    1-D torch.uint8 tensor on any device, possibly empty).  MD5 is a chain over the bytes in order, so one agent
+    has to see them all: ranks 1.. send theirs to rank 0 in chunks, rank 0 hashes on the host as they arrive.
+    Returns the 16-byte digest on rank 0, None elsewhere.  Point-to-point only; works over RCCL and gloo."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    md = hashlib.md5()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        md.update(local_pcm.cpu().numpy().tobytes())
+        return md.digest()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    size = torch.tensor([local_pcm.numel()], dtype=torch.int64, device=local_pcm.device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(x.item()) for x in sizes]
+    if rank == 0:
+        for off in range(0, sizes[0], chunk_bytes):
+            md.update(local_pcm[off: off + chunk_bytes].cpu().numpy().tobytes())
+        for src in range(1, world):
+            for off in range(0, sizes[src], chunk_bytes):
+                buf = torch.empty(min(chunk_bytes, sizes[src] - off), dtype=torch.uint8, device=local_pcm.device)
+                dist.recv(buf, src=src)
+                md.update(buf.cpu().numpy().tobytes())
+        return md.digest()
+    for off in range(0, sizes[rank], chunk_bytes):
+        dist.send(local_pcm[off: off + chunk_bytes].contiguous(), dst=0)
+    return None

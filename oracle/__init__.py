@@ -57,6 +57,9 @@ class Stats(ctypes.Structure):
         ("frames", ctypes.c_uint64),
         ("frames_ok", ctypes.c_uint64),
         ("samples", ctypes.c_uint64),
+        ("first_bad_frame", ctypes.c_uint64),
+        ("first_error", ctypes.c_int32),
+        ("pad", ctypes.c_uint32),
     ]
 
 
@@ -96,6 +99,10 @@ def lib():
         L.orc_decode_stream.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(StreamInfo),
                                         ctypes.c_void_p, ctypes.c_size_t,
                                         ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(Stats)]
+        L.orc_decode_stream_ex.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(StreamInfo),
+                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64,
+                                           ctypes.POINTER(Frame), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                                           ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(Stats)]
         L.orc_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.POINTER(StreamInfo), ctypes.c_uint32, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -163,6 +170,23 @@ def decode_stream(audio, si: StreamInfo, pcm_cap=None):
     if rc:
         raise RuntimeError(f"orc_decode_stream: status {rc}")
     return pcm[: n.value], st
+
+
+def decode_range(audio, si: StreamInfo, sample_base=0, pcm_cap=None):
+    """A frame range of a stream decoded on its own: the sample with index sample_base lands at byte 0.
+    Returns (pcm, Stats, list[Frame] with the statuses the decode left)."""
+    a = np.ascontiguousarray(np.frombuffer(audio, dtype=np.uint8))
+    cap = pcm_bytes(si) if pcm_cap is None else pcm_cap
+    pcm = np.zeros(cap, dtype=np.uint8)
+    fcap = a.size // 10 + 16
+    frames = (Frame * fcap)()
+    n, nf = ctypes.c_size_t(), ctypes.c_size_t()
+    st = Stats()
+    rc = lib().orc_decode_stream_ex(a.ctypes.data, a.size, ctypes.byref(si), pcm.ctypes.data, cap, int(sample_base),
+                                    frames, fcap, ctypes.byref(nf), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError(f"orc_decode_stream_ex: status {rc}")
+    return pcm[: n.value], st, [frames[i] for i in range(nf.value)]
 
 
 def decode_batch(data: np.ndarray, offs, lens, infos, pcm: np.ndarray, pcm_offs, pcm_caps, nthreads=1):

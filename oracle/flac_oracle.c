@@ -229,6 +229,7 @@ int orc_scan_frames(const uint8_t *data, size_t len, const orc_streaminfo *si,
     init_tabs();
     orc_stats st;
     memset(&st, 0, sizeof st);
+    st.first_bad_frame = ~(uint64_t)0;
 
     /* pass 1: candidates */
     size_t ccap = 1024, nc = 0;
@@ -266,6 +267,7 @@ int orc_scan_frames(const uint8_t *data, size_t len, const orc_streaminfo *si,
         }
         nf++;
         if (ok) { st.frames_ok++; st.samples += f.blocksize; }
+        else if (st.first_bad_frame == ~(uint64_t)0) { st.first_bad_frame = nf - 1; st.first_error = f.status; }
         cur = next;
     }
     st.frames = nf;
@@ -487,6 +489,14 @@ int orc_decode_frame(const uint8_t *frame, size_t len, const orc_streaminfo *si,
 int orc_decode_stream(const uint8_t *data, size_t len, const orc_streaminfo *si,
                       uint8_t *pcm, size_t pcm_cap, size_t *pcm_len, orc_stats *stats)
 {
+    return orc_decode_stream_ex(data, len, si, pcm, pcm_cap, 0, NULL, 0, NULL, pcm_len, stats);
+}
+
+int orc_decode_stream_ex(const uint8_t *data, size_t len, const orc_streaminfo *si,
+                         uint8_t *pcm, size_t pcm_cap, uint64_t sample_base,
+                         orc_frame *frames_out, size_t frames_cap, size_t *n_frames,
+                         size_t *pcm_len, orc_stats *stats)
+{
     if (!data || !si || !pcm) return ORC_ERR_ARG;
     size_t nf = 0;
     orc_stats st;
@@ -506,22 +516,30 @@ int orc_decode_stream(const uint8_t *data, size_t len, const orc_streaminfo *si,
         orc_frame *f = &frames[i];
         if (f->status != ORC_FRAME_OK) continue;
         uint64_t endsample = f->first_sample + f->blocksize;
-        if ((si->total_samples && endsample > si->total_samples) ||
-            endsample * (uint64_t)nch * bytes > pcm_cap) { f->status = ORC_FRAME_RANGE; continue; }
+        if ((si->total_samples && endsample > si->total_samples) || f->first_sample < sample_base ||
+            (endsample - sample_base) * (uint64_t)nch * bytes > pcm_cap) { f->status = ORC_FRAME_RANGE; continue; }
         int s = orc_decode_frame(data + f->offset, f->length, si, tmp, (size_t)nch * si->max_blocksize, NULL);
         f->status = s;
         if (s != ORC_FRAME_OK) continue;
-        uint8_t *o = pcm + f->first_sample * (uint64_t)nch * bytes;
+        uint8_t *o = pcm + (f->first_sample - sample_base) * (uint64_t)nch * bytes;
         for (uint32_t n = 0; n < f->blocksize; n++)
             for (int c = 0; c < nch; c++) {
                 uint32_t v = (uint32_t)tmp[(size_t)c * f->blocksize + n];
                 for (int k = 0; k < bytes; k++) *o++ = (uint8_t)(v >> (8 * k));
             }
-        size_t e = (size_t)(endsample * (uint64_t)nch * bytes);
+        size_t e = (size_t)((endsample - sample_base) * (uint64_t)nch * bytes);
         if (e > maxend) maxend = e;
         st.frames_ok++;
         st.samples += f->blocksize;
     }
+    st.first_bad_frame = ~(uint64_t)0;
+    st.first_error = 0;
+    st.pad = 0;
+    for (size_t i = 0; i < nf; i++)
+        if (frames[i].status != ORC_FRAME_OK) { st.first_bad_frame = i; st.first_error = frames[i].status; break; }
+    if (frames_out)
+        for (size_t i = 0; i < nf && i < frames_cap; i++) frames_out[i] = frames[i];
+    if (n_frames) *n_frames = nf;
     free(tmp);
     free(frames);
     if (pcm_len) *pcm_len = maxend;

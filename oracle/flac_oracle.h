@@ -79,6 +79,9 @@ typedef struct {
     uint64_t frames;            /* resolved frames (any status)              */
     uint64_t frames_ok;         /* status == ORC_FRAME_OK after decode/scan  */
     uint64_t samples;           /* inter-channel samples in OK frames        */
+    uint64_t first_bad_frame;   /* index of the first frame whose status is not OK after the decode; ~0 = none */
+    int32_t  first_error;       /* its ORC_FRAME_* status, 0 when there is none */
+    uint32_t pad;
 } orc_stats;
 
 /* flacmeta.go:644-717 (with MinFrameSize masked to 24 bits, see :699). */
@@ -103,6 +106,15 @@ int orc_decode_frame(const uint8_t *frame, size_t len, const orc_streaminfo *si,
  * frames are written at first_sample, so dropped frames leave a gap. */
 int orc_decode_stream(const uint8_t *data, size_t len, const orc_streaminfo *si,
                       uint8_t *pcm, size_t pcm_cap, size_t *pcm_len, orc_stats *stats);
+
+/* The same for a frame range of a stream: the sample with inter-channel index sample_base lands at pcm[0]
+ * (frames that start before it get ORC_FRAME_RANGE), and the frame table as the decode left it (statuses
+ * include what the subframe decoder found) is copied to frames_out when that is not NULL (frames_cap
+ * entries; *n_frames = frames found). */
+int orc_decode_stream_ex(const uint8_t *data, size_t len, const orc_streaminfo *si,
+                         uint8_t *pcm, size_t pcm_cap, uint64_t sample_base,
+                         orc_frame *frames_out, size_t frames_cap, size_t *n_frames,
+                         size_t *pcm_len, orc_stats *stats);
 
 /* Multi-threaded batch wrapper used for CPU-baseline timing: n independent
  * streams, statically partitioned over nthreads POSIX threads. */

@@ -84,6 +84,7 @@ static void mono(const std::string &dir, bool gpu)
         const std::string e = dec.DecodeFrames(got, f, pcm, r);
         CHECK(e.empty());
         CHECK(r.Frames == 248 && r.FramesOK == 248 && r.Samples == 1014300);
+        CHECK(r.FirstBadFrame == ~0ull && r.FirstError == 0 && r.MD5Status == FLACGPU_MD5_MATCH);
         CHECK(md5hex(pcm) == si.MD5Signature);
     }
 }
@@ -142,7 +143,22 @@ static void stereo(const std::string &dir, bool gpu)
         flac::StreamResult r;
         CHECK(dec.DecodeFrames(got, f, pcm, r).empty());
         CHECK(r.Frames == 36 && r.FramesOK == 36 && r.Samples == 162496);
+        CHECK(r.FirstBadFrame == ~0ull && r.MD5Status == FLACGPU_MD5_MATCH);
         CHECK(md5hex(pcm) == si.MD5Signature);
+        {
+            // one flipped bit inside frame 3's residual: the error names the frame, the other frames decode
+            std::ifstream h(dir + "/silence-44-s.flac", std::ios::binary);
+            std::string bytes((std::istreambuf_iterator<char>(h)), std::istreambuf_iterator<char>());
+            bytes[4186 + 1316 + 1319 + 1321 + 700] ^= 0x10;
+            std::istringstream hs(bytes);
+            flac::Metadata m2;
+            CHECK(m2.Read(hs).empty());
+            std::vector<uint8_t> pcm3;
+            flac::StreamResult r3;
+            const std::string e3 = dec.DecodeFrames(m2, hs, pcm3, r3);
+            CHECK(r3.FirstBadFrame == 3 && r3.FirstError == FLACGPU_FRAME_BAD_CRC16 && r3.FramesOK == 35);
+            CHECK(e3 == "decode: frame 3: CRC-16 mismatch");
+        }
         // write side: the PCM just decoded goes through EncodeBatch, the result through Read and DecodeFrames again
         std::vector<std::vector<uint8_t>> files;
         flac::Decoder::EncodeOptions eo;

@@ -24,10 +24,10 @@ def test_shard_indices_partition():
         sharding.shard_indices(4, 2, 2)
 
 
-def _run(world, out, port):
+def _run(world, out, port, worker="_shard_worker.py", *extra):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "_shard_worker.py"), out]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, worker), out, *extra]
     subprocess.run(cmd, check=True, env=env, timeout=240, cwd=os.path.dirname(HERE))
     return json.load(open(out))
 
@@ -54,3 +54,37 @@ def test_range_shards_cover_the_stream():
         assert len(sh) <= parts
     assert sharding.range_shards([], 500, 4) == [(0, 500)]
     assert len(sharding.range_shards(pts, 40000, 8)) == 8
+
+
+def check_range_run(r, world):
+    """What a frame-range run must show: the ranges tile the stream, every rank decoded every frame of its range,
+    the samples add up, and the MD5 finished on rank 0 is the stream's."""
+    shards = r["shards"]
+    assert r["world"] == world and len(shards) == world
+    assert shards[0][0] == 0 and shards[0][2] == 0
+    assert all(a[0] + a[1] == b[0] and a[2] + a[3] == b[2] for a, b in zip(shards[:-1], shards[1:]))
+    assert sum(s[3] for s in shards) == r["total_samples"]
+    t = np.array(r["table"])
+    assert (t[:, 1] == t[:, 2]).all() and (t[:, 1] > 0).all() and (t[:, 4] == 0).all()
+    assert [int(v) for v in t[:, 3]] == [s[3] for s in shards]
+    assert r["md5"] == r["streaminfo_md5"]
+
+
+def test_one_stream_cut_by_frame_range_over_two_ranks(tmp_path):
+    """One 24-bit 8-channel stream, split at seek points (flacmeta.go:612-641) over the ranks; the chained MD5 of
+    the stream is finished on rank 0 from the ranges' PCM and equals STREAMINFO's."""
+    check_range_run(_run(1, str(tmp_path / "r1.json"), 29613, "_range_worker.py"), 1)
+    check_range_run(_run(2, str(tmp_path / "r2.json"), 29614, "_range_worker.py"), 2)
+    check_range_run(_run(3, str(tmp_path / "r3.json"), 29615, "_range_worker.py"), 3)
+
+
+def test_range_shards_with_samples():
+    class P:
+        def __init__(self, s, o):
+            self.sample_number, self.offset = s, o
+    pts = [P(i * 4096, i * 1000) for i in range(0, 40)] + [P(0xFFFFFFFFFFFFFFFF, 0)]
+    sh = sharding.range_shards_with_samples(pts, 40000, 40 * 4096 - 7, 4)
+    assert len(sh) == 4 and sh[0][:3] == (0, 10000, 0)
+    assert all(b == o // 1000 * 4096 for o, _, b, _ in sh)
+    assert sum(n for _, _, _, n in sh) == 40 * 4096 - 7
+    assert sharding.my_range(sh, 3, 4) == sh[3] and sharding.my_range(sh[:2], 3, 4) is None

@@ -61,6 +61,31 @@ def test_noalloc_equals_the_handle_entry_point_twice_in_a_row(decoder):
         assert all(r[2] == r[1] and r[3] == si.total_samples for r, si in zip(ress[1], infos))
 
 
+def test_noalloc_leaves_device_memory_alone(decoder):
+    """What the entry point is named for: after a first call on the device (which only looks its workspace up), no
+    call changes the amount of free device memory, whatever the batch."""
+    import torch
+    enc = [encode_case(i, c) for i, c in enumerate(CASES)]
+    big = [f for _, f, _ in enc if len(f) < 400_000]
+    small = [f for name, f, _ in enc if name in ("tiny", "mono8", "stereo16-odd-bs")]
+    prepared = []
+    for files in (small, big, small):
+        infos, audios, in_offs, out_offs, host, out_bytes = _layout(files)
+        d_in = torch.from_numpy(host).cuda()
+        d_out = torch.zeros(out_bytes, dtype=torch.uint8, device="cuda")
+        streams = decoder.make_streams((in_offs[i], len(audios[i]), out_offs[i], infos[i].pcm_bytes, infos[i])
+                                       for i in range(len(files)))
+        prepared.append((d_in, host.size, d_out, out_bytes, streams))
+    flac_amd.decode_batch_device_noalloc(0, *prepared[0])               # warm-up: symbol lookup, CRC tables
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for args in prepared[1:]:                                            # a larger batch, then a smaller one
+        res = flac_amd.decode_batch_device_noalloc(0, *args)
+        torch.cuda.synchronize()
+        assert all(r.frames_ok == r.frames and r.frames for r in res)
+        assert torch.cuda.mem_get_info()[0] == free0
+
+
 def test_noalloc_limits_are_refused(decoder):
     import torch
     f = encode_case(0, CASES[0])[1]
