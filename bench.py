@@ -175,6 +175,18 @@ def self_launch(args, argv):
     sys.exit(subprocess.call(cmd))
 
 
+def resolve_gpus(gpus_arg, environ):
+    """Number of ranks: --gpus when given, else the launcher's WORLD_SIZE (a plain `torchrun --nproc-per-node=N
+    bench.py` works), else 1.  Returns (gpus, None) or (gpus, why the run is refused): an explicit --gpus that
+    contradicts the launcher is an error, not something to guess about."""
+    world = environ.get("WORLD_SIZE")
+    if gpus_arg is None:
+        return (int(world) if world is not None else 1), None
+    if world is not None and int(world) != gpus_arg:
+        return gpus_arg, f"--gpus {gpus_arg} but WORLD_SIZE is {world}"
+    return gpus_arg, None
+
+
 def workload_tag(args):
     """Names the stream shape a counter profile was taken on (stored in profiles/*pmc_traffic*.json)."""
     return (f"{args.rate}Hz_{args.bps}bit_{args.channels}ch_bs{args.blocksize}_lpc{args.lpc_order}_force{args.force_lpc_order}"
@@ -194,6 +206,14 @@ def dominant_decode_kernel(classes, channels, bytes_ps):
 
 
 def lookup_traffic(tag, kernel, nfiles):
+    """HBM traffic of `kernel` from the newest committed counter profile of this workload (profiles/*pmc_traffic*.json),
+    scaled by file count.  Returns (traffic bytes or None, details dict).  Counters cannot be read from inside this
+    process, so the figure comes from a rocprofv3 --pmc run of this same command at fewer files.  The write side
+    (WRITE_SIZE) needs no correction.  The read side is reported three ways: raw FETCH_SIZE, the request-size split
+    (128-byte requests x 128 + 32-byte requests x 32 + the others x 64, from TCC_BUBBLE / TCC_EA0_RDREQ_32B /
+    TCC_EA0_RDREQ) when the profile has that pass,
+    and raw x 2, the upper bound that holds if every request were a 128-byte one tallied at 64 (true for wide
+    coalesced reads on gfx950).  `traffic` uses the split when present, else the raw figure."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
@@ -201,19 +221,59 @@ def lookup_traffic(tag, kernel, nfiles):
             if pmc.get("workload_tag") != tag or kernel not in pmc["kernels"]:
                 continue
             kd = pmc["kernels"][kernel]
-            # read-side correction per kernel family (see the note in the json): 2 for wide coalesced reads, the
-            # calibrated value where the profile states one
-            factor = 2.0
-            for prefix, f in pmc.get("fetch_factor", {}).items():
-                if kernel.startswith(prefix):
-                    factor = float(f)
-            traffic = (factor * kd["FETCH_SIZE_KiB"] + kd["WRITE_SIZE_KiB"]) * 1024.0 * nfiles / pmc["files"]
-            return traffic, (f"({factor:g} x FETCH_SIZE + WRITE_SIZE) of {kernel} from {os.path.relpath(path, ROOT)}, measured at "
-                             f"{pmc['files']} files of this workload and scaled to {nfiles}; read-side factor as calibrated in "
-                             f"that file's note")
+            scale = nfiles / pmc["files"]
+            raw = kd["FETCH_SIZE_KiB"] * 1024.0 * scale
+            wr = kd["WRITE_SIZE_KiB"] * 1024.0 * scale
+            split = None
+            if "TCC_EA0_RDREQ" in kd and "TCC_EA0_RDREQ_32B" in kd and "TCC_BUBBLE" in kd:
+                # requests by size: TCC_BUBBLE counts the 128-byte ones, TCC_EA0_RDREQ_32B the 32-byte ones, the rest are 64
+                split = (kd["TCC_BUBBLE"] * 128.0 + kd["TCC_EA0_RDREQ_32B"] * 32.0
+                         + (kd["TCC_EA0_RDREQ"] - kd["TCC_BUBBLE"] - kd["TCC_EA0_RDREQ_32B"]) * 64.0) * scale
+            read = split if split is not None else raw
+            return read + wr, {"profile": os.path.relpath(path, ROOT), "profile_commit": pmc.get("commit"),
+                               "files_profiled": pmc["files"], "write_bytes": wr, "read_bytes_fetch_size_raw": raw,
+                               "read_bytes_request_split": split, "read_bytes_upper_bound_x2": 2.0 * raw,
+                               "read_side_used": "request split" if split is not None else "raw FETCH_SIZE"}
         except (OSError, KeyError, ValueError, TypeError):
             continue
-    return None, f"no committed counter profile of {kernel} on workload {tag}"
+    return None, {"note": f"no committed counter profile of {kernel} on workload {tag}"}
+
+
+def lookup_valu(tag, kernel):
+    """Vector instructions per sample step of `kernel` (SQ_INSTS_VALU / waves / block size) from the newest committed
+    SQ counter profile of this workload (profiles/*pmc_valu*.json), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_valu*.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            if pmc.get("workload_tag") == tag and kernel in pmc["kernels"]:
+                return float(pmc["kernels"][kernel]["valu_per_sample_step"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
+
+
+def device_description(torch, dev):
+    prop = torch.cuda.get_device_properties(dev)
+    return {"name": prop.name, "arch": getattr(prop, "gcnArchName", None), "compute_units": prop.multi_processor_count,
+            "hbm_GB": prop.total_memory / 1e9, "clock_MHz": getattr(prop, "clock_rate", 0) / 1e3 or None,
+            "l2_MB": getattr(prop, "L2_cache_size", 0) / 1e6 or None}
+
+
+def valu_issue(tag, kernel, values, seconds, device):
+    """How much of the chip's vector-instruction issue the decode kernel's launch used: its vector instructions per
+    sample step (one wave instruction covers one sample of 64 subframes) from the committed SQ profile of this
+    workload, times the launch's sample steps, over issue_peak = CUs x 4 SIMDs x clock / 4 cycles per instruction."""
+    per_step, src = lookup_valu(tag, kernel)
+    if per_step is None or seconds <= 0 or not device.get("clock_MHz"):
+        return None
+    clock = device["clock_MHz"] * 1e6
+    peak = device["compute_units"] * 4 * clock / 4.0
+    rate = per_step * (values / 64.0) / seconds
+    return {"insts_per_sample_step": per_step, "source": src, "sample_steps_per_launch": values / 64.0,
+            "issue_peak_per_s": peak, "frac": rate / peak, "clock_MHz_nominal": device["clock_MHz"],
+            # the clock at which the launch's instructions alone would fill every issue slot of its duration
+            "clock_MHz_if_all_slots_filled": device["clock_MHz"] * rate / peak}
 
 
 def host_description():
@@ -232,65 +292,14 @@ def host_description():
     return {"cpu_model": model, "cpu_count": os.cpu_count(), "cpus_usable": usable}
 
 
-def main(argv=None):
-    argv = sys.argv[1:] if argv is None else argv
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--config", choices=sorted(PRESETS), default="cfg3", help="named workload; explicit options override it")
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--files", type=int, default=10000)
-    ap.add_argument("--unique", type=int, default=256)
-    ap.add_argument("--seconds", type=float, default=60.0)
-    # the defaults are the headline workload; the options below exist to time other stream shapes
-    ap.add_argument("--rate", type=int, default=44100)
-    ap.add_argument("--channels", type=int, default=2)
-    ap.add_argument("--bps", type=int, default=16)
-    ap.add_argument("--blocksize", type=int, default=4096)
-    ap.add_argument("--lpc-order", type=int, default=12, help="maximum LPC order")
-    ap.add_argument("--force-lpc-order", type=int, default=0)
-    ap.add_argument("--partition-order", type=int, default=6, help="maximum Rice partition order")
-    ap.add_argument("--force-partition-order", type=int, default=-1)
-    ap.add_argument("--cpu-files", type=int, default=256, help="files of the workload timed on the host CPU (0 = skip)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU sample is decoded repeatedly for about this long")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
-    ap.add_argument("--host-files", type=int, default=128, help="files decoded through the host-buffer entry point for the PCIe-inclusive rate (0 = skip)")
-    ap.add_argument("--encode-steps", type=int, default=2, help="timed steps of the encode leg (0 = skip it)")
-    ap.add_argument("--stereo-mode", type=int, default=-2,
-                    help="encode leg: -2 stereo pair estimated per frame (two channels planned), -1 all four candidate "
-                         "channels planned and the cheapest pair taken, 0..3 one pair for every frame")
-    pre = ap.parse_known_args(argv)[0]
-    ap.set_defaults(**PRESETS[pre.config])
-    args = ap.parse_args(argv)
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args, argv)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
-        sys.exit(2)
-
+def run_workload(args, env):
+    """One file-sharded workload on every rank; returns the result line (a dict) on rank 0, None elsewhere."""
     import torch
     import flac_amd
     import synth
-
-    # FLAC_BENCH_REHEARSE=1: every rank on GPU 0 and gloo for the timing scalars, to run the multi-rank path
-    # on a one-GPU box (RCCL refuses two ranks on one device); never set for a measurement
-    rehearse = bool(os.environ.get("FLAC_BENCH_REHEARSE"))
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    red_dev = torch.device("cpu") if rehearse else dev
+    rank, local_rank, world, dev, red_dev = env["rank"], env["local_rank"], env["world"], env["dev"], env["red_dev"]
     if world > 1:
         import torch.distributed as dist
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
     rate, channels, bps, blocksize = args.rate, args.channels, args.bps, args.blocksize
     nsamples = int(round(args.seconds * rate))
     bytes_ps = (bps + 7) // 8
@@ -487,6 +496,7 @@ def main(argv=None):
                         "(copy in, decode and copy out of consecutive chunks overlap)"}
         del h_pcm
 
+    result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         alg_bytes = comp_total + pcm_total            # per launch of the decode kernel (one rank)
@@ -497,11 +507,9 @@ def main(argv=None):
         # this same kernel instantiation, scaled by file count; none that matches -> null
         dominant = dominant_decode_kernel(dec.timing().decode_classes, channels, bytes_ps)
         traffic, traffic_note = lookup_traffic(workload_tag(args), dominant, nfiles)
-        prop = torch.cuda.get_device_properties(dev)
-        device = {"name": prop.name, "arch": getattr(prop, "gcnArchName", None), "compute_units": prop.multi_processor_count,
-                  "hbm_GB": prop.total_memory / 1e9, "clock_MHz": getattr(prop, "clock_rate", 0) / 1e3 or None,
-                  "l2_MB": getattr(prop, "L2_cache_size", 0) / 1e6 or None}
+        device = device_description(torch, dev)
         tot_s = kernel_ms["total_ms"] / 1e3
+        valu = valu_issue(workload_tag(args), dominant, values_total, dec_s, device)
         out = {
             "metric": "decoded PCM samples/sec",
             "value": values_all * args.steps / elapsed,
@@ -528,8 +536,11 @@ def main(argv=None):
             "algorithmic_GB_per_s": (pcm_all + comp_all) * args.steps / elapsed / 1e9,
             "kernel_ms": kernel_ms,
             "rank_ms_per_step": rank_ms,
+            # priced against the HBM roofline (algorithmic bytes over the peak); what the counters show the kernel is held
+            # up by is in limited_by, with the vector-issue fraction beside it
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_detail": traffic_note,
+                         "limited_by": "valu_issue" if valu else None, "valu": valu,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms["decode_ms"],
                          # every kernel of the batch (scan .. results) against the same algorithmic bytes
                          "pipeline_frac": alg_bytes / tot_s / 8e12 if tot_s > 0 else 0.0, "pipeline_ms": kernel_ms["total_ms"]},
@@ -540,8 +551,238 @@ def main(argv=None):
             "md5_verified": md5_check,
             "encode": enc,
         }
+        result = out
+    dec.close()
+    del d_out
+    torch.cuda.empty_cache()
+    return result
+
+
+def run_range(args, env):
+    """--shard range: ONE stream of args.seconds, cut at its seek points (SeekpointBlock, flacmeta.go:256-260) into one
+    frame range per rank.  Every rank builds the same stream on its own GPU (synthetic PCM of a few seconds repeated,
+    encoded by the GPU encoder with a seek table), decodes its range into a region of its own (sample_base), and
+    the stream's MD5, a chain over all its PCM in order, is finished on rank 0 from the ranges.  Strong scaling:
+    the stream is fixed, a rank's share shrinks with the number of ranks."""
+    import hashlib
+    import torch
+    import flac_amd
+    import synth
+    from flac_amd import sharding
+    rank, local_rank, world, dev, red_dev = env["rank"], env["local_rank"], env["world"], env["dev"], env["red_dev"]
+    if world > 1:
+        import torch.distributed as dist
+    rate, channels, bps, blocksize = args.rate, args.channels, args.bps, args.blocksize
+    bytes_ps = (bps + 7) // 8
+    fb = channels * bytes_ps
+    n_unit = max(blocksize, int(round(min(args.seconds, 5.0) * rate)) // blocksize * blocksize)   # a few seconds, whole blocks
+    reps = max(1, int(round(args.seconds * rate / n_unit)))
+    nsamples = n_unit * reps
+    x = synth.pcm(0xA11, n_unit, channels, bps, rate, blocksize)
+    unit = np.frombuffer(synth.pack_pcm(x, bps), dtype=np.uint8)
+    md = hashlib.md5()
+    for _ in range(reps):
+        md.update(unit.tobytes())
+    want_md5 = md.digest()
+    pcm_total = nsamples * fb
+    d_pcm = torch.from_numpy(unit.copy()).to(dev).repeat(reps)
+    pad = torch.zeros(256, dtype=torch.uint8, device=dev)
+    d_pcm = torch.cat([d_pcm, pad])
+    dec = flac_amd.Decoder(local_rank, timing=True)
+    hip_stream = torch.cuda.current_stream(dev).cuda_stream
+    cap = flac_amd.encode_bound(nsamples, channels, bps, blocksize, args.seek_frames)
+    d_enc = torch.empty(cap + 256, dtype=torch.uint8, device=dev)
+    opts = flac_amd.encode_options(blocksize=blocksize, max_lpc_order=args.lpc_order,
+                                   max_partition_order=(args.force_partition_order if args.force_partition_order >= 0 else args.partition_order),
+                                   min_partition_order=max(0, args.force_partition_order), force_lpc_order=args.force_lpc_order,
+                                   stereo_mode=args.stereo_mode, seektable_interval=args.seek_frames)
+    es = dec.make_pcm_streams([(0, nsamples, 0, cap, rate, channels, bps, want_md5)])
+    eres = dec.encode_batch_device(d_pcm, pcm_total, d_enc, cap + 256, es, opts, hip_stream=hip_stream)
+    assert eres[0].status == 0, "the stream did not fit its capacity"
+    flac_len = int(eres[0].out_length)
+    del d_pcm
+    torch.cuda.empty_cache()
+    head_len = min(flac_len, 42 + 4 + 18 * (nsamples // blocksize // args.seek_frames + 2) + 64)
+    head = d_enc[:head_len].cpu().numpy().tobytes()
+    mdt = flac_amd.parse_metadata(head)
+    seek = [b for b in mdt.blocks[: mdt.n_blocks] if b.type == 4][0]
+    pts = flac_amd.parse_seektable(head[seek.payload_offset: seek.payload_offset + seek.length])
+    si = flac_amd.StreamInfo()
+    ctypes.memmove(ctypes.byref(si), ctypes.byref(mdt.streaminfo), ctypes.sizeof(si))
+    assert bytes(si.md5) == want_md5 and si.total_samples == nsamples
+    ff = int(mdt.first_frame_offset)
+    audio_len = flac_len - ff
+    shards = sharding.range_shards_with_samples(pts, audio_len, nsamples, world)
+    mine = sharding.my_range(shards, rank, world)
+    if rank == 0:
+        log(f"one stream: {args.seconds:g} s, {flac_len / 1e9:.2f} GB FLAC for {pcm_total / 1e9:.2f} GB PCM, {len(pts)} seek points, "
+            f"{len(shards)} frame ranges over {world} rank(s)")
+    # the decoder wants d_in 16-byte aligned: the stream starts at d_enc, ranges are offsets into it
+    if mine is None:
+        off = n = base = ns = 0
+    else:
+        off, n, base, ns = mine
+    my_cap = ns * fb
+    d_out = torch.empty(my_cap + 256, dtype=torch.uint8, device=dev)
+    streams = dec.make_streams([(ff + off, n, 0, my_cap, si, base)]) if mine is not None else None
+    results = (flac_amd.StreamResult * 1)()
+
+    def step():
+        if streams is not None:
+            dec.decode_batch_device(d_enc, flac_len + 16, d_out, my_cap + 256, streams, hip_stream=hip_stream, results=results)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    kernel_ms = {k: 0.0 for k in ("scan_ms", "compact_ms", "crc16_ms", "resolve_ms", "skim_ms", "decode_ms", "results_ms", "total_ms")}
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t = dec.timing()
+        for k in kernel_ms:
+            kernel_ms[k] += getattr(t, k) / args.steps
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
+    if world > 1:
+        mine_t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        every = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(every, mine_t)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)
+    # what every rank decoded, gathered as rows; the stream's MD5 finished on rank 0 from the ranges' PCM
+    rows = sharding.result_rows([rank] if mine is not None else [], [results[0]] if mine is not None else [])
+    table = sharding.gather_rows(rows, len(shards), device=None if env["rehearse"] or world == 1 else dev)
+    t0 = time.perf_counter()
+    local = d_out[:my_cap]
+    digest = sharding.chained_md5(local.cpu() if env["rehearse"] else local)
+    md5_s = time.perf_counter() - t0
+    result = None
+    if rank == 0:
+        assert int(table[:, 1].sum()) == int(table[:, 2].sum()) and int(table[:, 3].sum()) == nsamples, "a range did not decode completely"
+        assert digest == want_md5, "the stream's MD5, finished from the ranges, differs from STREAMINFO"
+        log(f"MD5 of the stream finished on rank 0 from {len(shards)} ranges: equals STREAMINFO ({md5_s:.1f} s)")
+        values = nsamples * channels
+        my_alg = n + my_cap
+        dec_s = kernel_ms["decode_ms"] / 1e3
+        tot_s = kernel_ms["total_ms"] / 1e3
+        dominant = dominant_decode_kernel(dec.timing().decode_classes, channels, bytes_ps)
+        result = {
+            "metric": "decoded PCM samples/sec", "value": values * args.steps / elapsed, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int32" if bps <= 16 else "int64", "data": "synthetic",
+            "config": {"name": args.config, "shard": "range", "workload_tag": workload_tag(args),
+                       "workload": f"one {args.seconds:g} s {rate / 1000:g} kHz {bps}-bit {channels}-channel stream, blocksize {blocksize}, "
+                                   f"cut at seek points into {len(shards)} frame ranges, one per rank",
+                       "ranges": [[int(v) for v in sh] for sh in shards], "compressed_GB": flac_len / 1e9, "pcm_GB": pcm_total / 1e9},
+            "pcm_MB_per_s": pcm_total * args.steps / elapsed / 1e6,
+            "kernel_ms": kernel_ms, "rank_ms_per_step": rank_ms,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": my_alg / dec_s / 1e9 if dec_s > 0 else 0.0, "peak": 8000.0,
+                         "unit": "GB/s", "frac": my_alg / dec_s / 8e12 if dec_s > 0 else 0.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": my_alg, "avg_launch_ms": kernel_ms["decode_ms"],
+                         "pipeline_frac": my_alg / tot_s / 8e12 if tot_s > 0 else 0.0,
+                         "note": "rank 0's range; a range of one stream holds few frames (one lane per subframe), so the launch "
+                                 "does not fill the chip: see the file-sharded configurations for the kernel's rate"},
+            "cpu_baseline": None,
+            "md5_verified": {"streams": 1, "ranges": len(shards), "seconds": md5_s, "finished_on": "rank 0, host, from the ranges' PCM in rank order"},
+            "device": device_description(torch, dev), "host": host_description(),
+        }
+    dec.close()
+    return result
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE when a launcher set it, else 1")
+    ap.add_argument("--config", choices=sorted(PRESETS), default="cfg3", help="named workload; explicit options override it")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--files", type=int, default=10000)
+    ap.add_argument("--unique", type=int, default=256)
+    ap.add_argument("--seconds", type=float, default=60.0)
+    # the defaults are the headline workload; the options below exist to time other stream shapes
+    ap.add_argument("--rate", type=int, default=44100)
+    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--bps", type=int, default=16)
+    ap.add_argument("--blocksize", type=int, default=4096)
+    ap.add_argument("--lpc-order", type=int, default=12, help="maximum LPC order")
+    ap.add_argument("--force-lpc-order", type=int, default=0)
+    ap.add_argument("--partition-order", type=int, default=6, help="maximum Rice partition order")
+    ap.add_argument("--force-partition-order", type=int, default=-1)
+    ap.add_argument("--cpu-files", type=int, default=256, help="files of the workload timed on the host CPU (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU sample is decoded repeatedly for about this long")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
+    ap.add_argument("--host-files", type=int, default=128, help="files decoded through the host-buffer entry point for the PCIe-inclusive rate (0 = skip)")
+    ap.add_argument("--encode-steps", type=int, default=2, help="timed steps of the encode leg (0 = skip it)")
+    ap.add_argument("--stereo-mode", type=int, default=-2,
+                    help="encode leg: -2 stereo pair estimated per frame (two channels planned), -1 all four candidate "
+                         "channels planned and the cheapest pair taken, 0..3 one pair for every frame")
+    ap.add_argument("--shard", choices=("file", "range"), default="file",
+                    help="file: every rank decodes its own batch of files (weak scaling).  range: ONE stream of --seconds, cut at "
+                         "seek points into one frame range per rank (strong scaling); its MD5 is finished on rank 0")
+    ap.add_argument("--seek-frames", type=int, default=16, help="--shard range: a seek point every this many frames")
+    ap.add_argument("--cfg4-files", type=int, default=256, help="files of the cfg4 leg appended to a cfg3 line (0 = no cfg4 leg)")
+    pre = ap.parse_known_args(argv)[0]
+    ap.set_defaults(**PRESETS[pre.config])
+    args = ap.parse_args(argv)
+
+    args.gpus, problem = resolve_gpus(args.gpus, os.environ)
+    if problem:
+        print("bench.py: " + problem, file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import flac_amd
+    import synth
+
+    # FLAC_BENCH_REHEARSE=1: every rank on GPU 0 and gloo for the timing scalars, to run the multi-rank path
+    # on a one-GPU box (RCCL refuses two ranks on one device); never set for a measurement
+    rehearse = bool(os.environ.get("FLAC_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if rehearse else dev
+    if world > 1:
+        import torch.distributed as dist
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    env = {"rank": rank, "local_rank": local_rank, "world": world, "dev": dev, "red_dev": red_dev, "rehearse": rehearse}
+    if args.shard == "range":
+        out = run_range(args, env)
+    else:
+        out = run_workload(args, env)
+        if args.config == "cfg3" and args.cfg4_files > 0:
+            # the 24-bit 8-channel configuration as a second, shorter leg of the same line
+            a4 = argparse.Namespace(**vars(args))
+            for k, v in PRESETS["cfg4"].items():
+                setattr(a4, k, v)
+            a4.config, a4.files, a4.steps, a4.warmup = "cfg4", args.cfg4_files, min(args.steps, 3), 1
+            a4.encode_steps, a4.host_files, a4.cpu_files, a4.cpu_seconds = 0, 0, (4 if args.cpu_files else 0), 5.0
+            sub = run_workload(a4, env)
+            if out is not None:
+                out["configs"] = {"cfg4": {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "pcm_MB_per_s",
+                                                                "algorithmic_GB_per_s", "kernel_ms", "roofline", "cpu_baseline",
+                                                                "md5_verified", "dtype")}}
+    if out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

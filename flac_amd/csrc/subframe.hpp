@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "device_types.hpp"
+#include "variants.hpp"
 
 namespace flacgpu {
 
@@ -35,29 +36,17 @@ namespace flacgpu {
 // owns a small ring in LDS that it refills 32 bytes (one sector) at a time
 // (ring_round).  A refill is issued one round (8 decode steps) before it is
 // written to the ring, so its latency overlaps decoding.
-#ifndef FLACGPU_RING_LOG2
-#define FLACGPU_RING_LOG2 5
-#endif
-constexpr uint32_t kRingLog2 = FLACGPU_RING_LOG2;
+constexpr uint32_t kRingLog2 = variant::kRingLog2;
 constexpr uint32_t kRingWords = 1u << kRingLog2;   // ring capacity per lane, in 32-bit words
 constexpr uint32_t kRingSlots = kRingWords + 1;    // the last slot repeats slot 0, so that words w and w + 1 are always one two-word read
 constexpr uint32_t kUnitWords = 8;    // refill granule: 32 bytes
-#ifndef FLACGPU_ROUND_STEPS
-#define FLACGPU_ROUND_STEPS 8
-#endif
-constexpr uint32_t kRoundSteps = FLACGPU_ROUND_STEPS;   // decode steps (of at most 32 bits) between refill rounds
+constexpr uint32_t kRoundSteps = variant::kRoundSteps;   // decode steps (of at most 32 bits) between refill rounds
 constexpr uint32_t kRingBytesPerWave = kRingSlots * 64 * 4;
 constexpr uint32_t kNoFill = 0xFFFFFFFFu;
 // A lane fetches its next unit when it has this many unread words or fewer.  The unit lands one round later
 // on the ring's oldest words, which the reader must have passed by then: at most kRingWords - kUnitWords.
 constexpr uint32_t kFetchBelow = kRingWords >= 32 ? 17 : kRingWords - kUnitWords;
-#ifndef FLACGPU_SKIM_PAIR_K
-#define FLACGPU_SKIM_PAIR_K 9
-#endif
-constexpr uint32_t kSkimPairK = FLACGPU_SKIM_PAIR_K;
-#ifndef FLACGPU_SKIM_WIDE
-#define FLACGPU_SKIM_WIDE 1   // 0: one code per 32-bit window where two do not fit one (the earlier loop)
-#endif
+constexpr uint32_t kSkimPairK = variant::kSkimPairK;
 // Compile-time loops: the body gets its index as a std::integral_constant (the unrolled loops index register arrays).
 template <int N, int I = 0, class F>
 __device__ inline void static_for_each(F &&f)
@@ -500,36 +489,36 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
                         Q -= tot;
                     }
                 } else {
-#if FLACGPU_SKIM_WIDE
-                    // two codes per 64-bit window: either code may be up to 32 bits long.  The OR of the lengths
-                    // exceeds 32 when one of them does (and, harmlessly, when one is exactly 32 beside another).
+                    if constexpr (variant::kSkimWide) {
+                        // two codes per 64-bit window: either code may be up to 32 bits long.  The OR of the lengths
+                        // exceeds 32 when one of them does (and, harmlessly, when one is exactly 32 beside another).
 #pragma unroll
-                    for (int P = 0; P < (int)G / 2; ++P) {
-                        if (2 * P == (int)kRoundSteps) {
-                            br.P = 0u - Q;
-                            starved = starved || br.starved();
-                            ring_round<true>(br, rf, reads);
+                        for (int P = 0; P < (int)G / 2; ++P) {
+                            if (2 * P == (int)kRoundSteps) {
+                                br.P = 0u - Q;
+                                starved = starved || br.starved();
+                                ring_round<true>(br, rf, reads);
+                            }
+                            const uint2 w = br.peek64_ring_neg(Q);
+                            const uint32_t n1 = __clz(w.x) + 1 + k;
+                            const uint32_t w2 = __builtin_amdgcn_alignbit(w.x, w.y, 32u - n1);   // the window n1 bits on (n1 <= 32, else the lane is redone)
+                            const uint32_t n2 = __clz(w2) + 1 + k;
+                            longest |= n1 | n2;
+                            Q -= n1 + n2;
                         }
-                        const uint2 w = br.peek64_ring_neg(Q);
-                        const uint32_t n1 = __clz(w.x) + 1 + k;
-                        const uint32_t w2 = __builtin_amdgcn_alignbit(w.x, w.y, 32u - n1);   // the window n1 bits on (n1 <= 32, else the lane is redone)
-                        const uint32_t n2 = __clz(w2) + 1 + k;
-                        longest |= n1 | n2;
-                        Q -= n1 + n2;
-                    }
-#else
+                    } else {
 #pragma unroll
-                    for (int P = 0; P < (int)G; ++P) {
-                        if (P == (int)kRoundSteps) {
-                            br.P = 0u - Q;
-                            starved = starved || br.starved();
-                            ring_round<true>(br, rf, reads);
+                        for (int P = 0; P < (int)G; ++P) {
+                            if (P == (int)kRoundSteps) {
+                                br.P = 0u - Q;
+                                starved = starved || br.starved();
+                                ring_round<true>(br, rf, reads);
+                            }
+                            const uint32_t nb = __clz(br.peek_ring_neg(Q)) + 1 + k;
+                            longest = max(longest, nb);
+                            Q -= nb;
                         }
-                        const uint32_t nb = __clz(br.peek_ring_neg(Q)) + 1 + k;
-                        longest = max(longest, nb);
-                        Q -= nb;
                     }
-#endif
                 }
                 br.P = 0u - Q;
                 starved = starved || br.starved();
@@ -1011,9 +1000,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
     };
     // Write-out of the staged samples [t0, t0 + kT) of every frame of this wave.
     auto flush = [&](uint32_t t0) {
-#ifdef FLACGPU_ABL_NOFLUSH   // ablation build: what the write-out costs in all
-        if (t0 != 0xFFFFFFF0u) return;
-#endif
+        if (variant::kNoFlush && t0 != 0xFFFFFFF0u) return;
         __builtin_amdgcn_wave_barrier();
         if (MONO16) {
             // a word of the tile is two consecutive samples of one frame, the later one in the low half; the
@@ -1031,9 +1018,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                         const uint32_t w = tile_raw[(cp4 + i) * kPairStride + it * 16 + (lane >> 2)];
                         word[i] = __builtin_amdgcn_alignbit(w, w, 16);
                     }
-#ifdef FLACGPU_ABL_NOSTORE
-                    if (word[0] == 0x12345678u && word[1] == 0x9abcdef0u && word[2] == word[3])
-#endif
+                    if (!variant::kNoStore16 || (word[0] == 0x12345678u && word[1] == 0x9abcdef0u && word[2] == word[3]))   // the words never have these values
                     *reinterpret_cast<uint4 *>(p.out + fdst[it] + (uint64_t)t0 * 2) = uint4{word[0], word[1], word[2], word[3]};
                 }
             } else {
@@ -1112,9 +1097,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                             word[i] = pack_lo_hi(L, R);
                         }
                     }
-#ifdef FLACGPU_ABL_NOSTORE   // ablation build: everything but the stores themselves (the words never have these values)
-                    if (word[0] == 0x12345678u && word[1] == 0x9abcdef0u && word[2] == word[3])
-#endif
+                    if (!variant::kNoStore16 || (word[0] == 0x12345678u && word[1] == 0x9abcdef0u && word[2] == word[3]))
                     *reinterpret_cast<uint4 *>(p.out + fdst[it] + (uint64_t)t0 * 4) = uint4{word[0], word[1], word[2], word[3]};
                 }
             } else {
@@ -1244,11 +1227,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                         // multi-dword global stores need dword alignment only; a wave's stores count against the
                         // same counter as its refill loads, so fewer and wider ones wait less
                         uint8_t *q = p.out + q_dst[0] + (uint64_t)t0 * CB;
-#ifdef FLACGPU_DEBUG_NO_STORE
-                        if (t0 != 0xFFFFFFF0u) q = nullptr;   // ablation build: what the stores of this path cost
-                        if (q)
-#endif
-                        {
+                        if (!(variant::kNoStoreGeneral && t0 != 0xFFFFFFF0u)) {
                             // the item's two runs of eight slots lie 8 * C slots apart
                             uint8_t *const q2 = q + 8 * CB;
                             if (B == 4) {
@@ -1300,9 +1279,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                         decorrelate(m, v[2], v[3], L, R); v[2] = L; v[3] = R;
                     }
                     uint8_t *q = p.out + q_dst[it] + (uint64_t)t0 * CB;
-#ifdef FLACGPU_DEBUG_NO_STORE
-                    if (t0 != 0xFFFFFFF0u) continue;
-#endif
+                    if (variant::kNoStoreGeneral && t0 != 0xFFFFFFF0u) continue;
                     if (B == 1) *reinterpret_cast<uint32_t *>(q) = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
                     else if (B == 2) *reinterpret_cast<Dwords2 *>(q) = Dwords2{(v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16)};
                     else if (B == 3) { uint32_t d0, d1, d2; pack(v, d0, d1, d2); *reinterpret_cast<Dwords3 *>(q) = Dwords3{d0, d1, d2}; }
@@ -1371,11 +1348,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                                       : (!on || (kind == 0 && const_fast && widemask_rest == 0) ||
                                          (rice_on && !escaped && part_rem >= (uint32_t)U && n0 + U <= bs && (!DOT || hist16)));
         bool redo = true;            // lanes the generic body below has to process
-#ifdef FLACGPU_DEBUG_NO_FAST
-        bool run_generic = true;
-#else
-        bool run_generic = !__all(simple);
-#endif
+        bool run_generic = variant::kNoFastGroups || !__all(simple);
         if (!run_generic) {
             // ---- fast group: U Rice codes per lane, speculatively and without branches ------
             // Every code is assumed to fit the 32-bit window and every word to be in the ring.
@@ -1422,10 +1395,9 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
                 constexpr int P = decltype(PC)::value;
                 const int32_t res = unzigzag(u);
                 int32_t pred;
-#ifdef FLACGPU_PROTO_NOPRED   // prototype build: what parsing and staging cost without the predictor (output is wrong)
-                if constexpr (DOT) { pred = 0; } else
-#endif
-                if constexpr (DOT) {
+                if constexpr (DOT && variant::kNoPredictor) {
+                    pred = 0;
+                } else if constexpr (DOT) {
                     // pair i = taps 2i and 2i + 1 = samples n - 1 - 2i and n - 2 - 2i = pk[(n - 1 - 2i) % U]; two chains,
                     // and the pair with the newest sample, the only one that waits for the previous result, last
                     // one chain, oldest pair first: only its last link waits for the previous sample
@@ -1476,13 +1448,9 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
             }
             br.P = 0u - Q;
             starved = starved || br.starved();
-#ifdef FLACGPU_DEBUG_FORCE_REDO
-            redo = rice_on;
-#else
             // q + 1 + k > 32 for some code?  The OR of the counts is at least their maximum (a zero window counts
             // as 2^32 - 1 zeros), so the test never misses one; it is wrong the safe way now and then.
-            redo = rice_on && (starved || longest_q > 31 - k);
-#endif
+            redo = rice_on && (variant::kForceRedo || starved || longest_q > 31 - k);
             govf = ((uint32_t)gmax + half_fast) | ((uint32_t)gmin + half_fast);   // in range exactly when both ends are
             // a sample that does not fit 16 bits (less its wasted bits: the tile holds 16) was multiplied and staged as if it did
             if (pair17) redo = redo || (rice_on && (govf >> fast_bits));

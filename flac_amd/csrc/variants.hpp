@@ -1,0 +1,73 @@
+// variants.hpp — compile-time switches of experiment builds.
+//
+// The product build defines none of the macros below: every ablation switch is false and the tuning constants
+// have the values that measured best.  scripts/build_variant.sh compiles the decode translation unit with some
+// of them set (-DFLACGPU_ABL_NOFLUSH ...) to time a kernel without one of its parts or with another ring
+// geometry; the kernels themselves only see the constants of this header.
+#pragma once
+
+#include <stdint.h>
+
+namespace flacgpu {
+namespace variant {
+
+#ifdef FLACGPU_ABL_NOFLUSH      // no write-out at all: what the write-out costs in all (output is wrong)
+constexpr bool kNoFlush = true;
+#else
+constexpr bool kNoFlush = false;
+#endif
+
+#ifdef FLACGPU_ABL_NOSTORE      // the 16-bit layouts' write-out without its stores (output is wrong)
+constexpr bool kNoStore16 = true;
+#else
+constexpr bool kNoStore16 = false;
+#endif
+
+#ifdef FLACGPU_DEBUG_NO_STORE   // the general layouts' write-out without its stores (output is wrong)
+constexpr bool kNoStoreGeneral = true;
+#else
+constexpr bool kNoStoreGeneral = false;
+#endif
+
+#ifdef FLACGPU_DEBUG_NO_FAST    // every group through the generic body
+constexpr bool kNoFastGroups = true;
+#else
+constexpr bool kNoFastGroups = false;
+#endif
+
+#ifdef FLACGPU_DEBUG_FORCE_REDO // every unrolled group rolled back and redone by the generic body
+constexpr bool kForceRedo = true;
+#else
+constexpr bool kForceRedo = false;
+#endif
+
+#ifdef FLACGPU_PROTO_NOPRED     // the 16-bit pair class without its predictor: what parsing and staging alone cost (output is wrong)
+constexpr bool kNoPredictor = true;
+#else
+constexpr bool kNoPredictor = false;
+#endif
+
+// ---- tuning constants
+#ifdef FLACGPU_RING_LOG2
+constexpr uint32_t kRingLog2 = FLACGPU_RING_LOG2;
+#else
+constexpr uint32_t kRingLog2 = 5;        // ring capacity per lane: 32 words
+#endif
+#ifdef FLACGPU_ROUND_STEPS
+constexpr uint32_t kRoundSteps = FLACGPU_ROUND_STEPS;
+#else
+constexpr uint32_t kRoundSteps = 8;      // decode steps between refill rounds
+#endif
+#ifdef FLACGPU_SKIM_PAIR_K
+constexpr uint32_t kSkimPairK = FLACGPU_SKIM_PAIR_K;
+#else
+constexpr uint32_t kSkimPairK = 9;       // largest Rice parameter for which the skim reads two codes per 32-bit window
+#endif
+#ifdef FLACGPU_SKIM_NARROW
+constexpr bool kSkimWide = false;        // one code per 32-bit window where two do not fit one (the earlier loop)
+#else
+constexpr bool kSkimWide = true;
+#endif
+
+}  // namespace variant
+}  // namespace flacgpu

@@ -2,7 +2,7 @@
 # A/B runs of library variants (variants/lib_<name>.so, or "tree" for the in-tree build) on one GPU box:
 # scripts/ab.sh [bench options --] name...   Stops at the first run that fails.
 set -e
-opts="--files 2000 --unique 128 --steps 3 --warmup 1 --cpu-files 0 --host-files 0 --encode-steps 0"
+opts="--files 2000 --unique 128 --steps 3 --warmup 1 --cpu-files 0 --host-files 0 --cfg4-files 0 --encode-steps 0"
 if [[ " $* " == *" -- "* ]]; then
     extra=""
     while [ "$1" != "--" ]; do extra="$extra $1"; shift; done

@@ -45,6 +45,15 @@ def test_world_size_must_match_gpus():
     assert p.returncode == 2 and "WORLD_SIZE is 3" in p.stderr
 
 
+def test_launcher_world_size_is_adopted_when_gpus_is_not_given():
+    assert bench.resolve_gpus(None, {}) == (1, None)
+    assert bench.resolve_gpus(None, {"WORLD_SIZE": "8"}) == (8, None)       # plain torchrun --nproc-per-node=8 bench.py
+    assert bench.resolve_gpus(4, {"WORLD_SIZE": "4"}) == (4, None)
+    assert bench.resolve_gpus(2, {}) == (2, None)                           # bench.py starts its own ranks
+    n, why = bench.resolve_gpus(2, {"WORLD_SIZE": "3"})
+    assert n == 2 and "WORLD_SIZE is 3" in why
+
+
 @pytest.mark.gpu
 def test_two_ranks_started_by_bench_itself():
     """`bench.py --gpus 2` with no launcher around it: two ranks (both on GPU 0, gloo for the timing scalars: a
@@ -53,7 +62,8 @@ def test_two_ranks_started_by_bench_itself():
     env["FLAC_BENCH_REHEARSE"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--files", "24", "--unique", "4",
                         "--seconds", "2", "--steps", "2", "--warmup", "1", "--cpu-files", "2", "--cpu-seconds", "0.2",
-                        "--encode-steps", "1", "--host-files", "6"], env=env, capture_output=True, text=True, timeout=900)
+                        "--encode-steps", "1", "--host-files", "6", "--cfg4-files", "0"], env=env, capture_output=True, text=True,
+                       timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -63,3 +73,34 @@ def test_two_ranks_started_by_bench_itself():
     assert 0 < out["roofline"]["pipeline_frac"] <= out["roofline"]["frac"] < 1
     assert out["pcie_inclusive"]["files"] == 6 and 0 < out["pcie_inclusive"]["value"] < out["value"]
     assert out["cpu_baseline"]["cores"] >= 1 and out["host"]["cpu_count"] >= 1 and out["device"]["compute_units"] > 0
+    assert "configs" not in out          # --cfg4-files 0
+
+
+@pytest.mark.gpu
+def test_cfg4_leg_rides_on_the_headline_line():
+    """The default command appends the 24-bit 8-channel configuration as configs.cfg4 with its own roofline,
+    CPU baseline and MD5 check (here at a few files)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FLAC_BENCH_REHEARSE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--files", "24", "--unique", "4", "--seconds", "2",
+                        "--steps", "2", "--warmup", "1", "--cpu-files", "2", "--cpu-seconds", "0.2", "--encode-steps", "0",
+                        "--host-files", "0", "--cfg4-files", "6"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c4 = out["configs"]["cfg4"]
+    assert out["config"]["name"] == "cfg3" and c4["config"]["name"] == "cfg4" and c4["config"]["files_per_gpu"] == 6
+    assert c4["value"] > 0 and c4["md5_verified"]["streams"] == 6 and c4["cpu_baseline"]["value"] > 0
+    assert c4["roofline"]["kernel"].startswith("k_decode<32, 2") and 0 < c4["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_one_stream_cut_over_two_ranks_by_the_bench():
+    """`bench.py --shard range --gpus 2`: one 24-bit 8-channel stream, a frame range per rank, MD5 finished on rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FLAC_BENCH_REHEARSE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg4", "--shard", "range", "--gpus", "2",
+                        "--seconds", "6", "--steps", "2", "--warmup", "1", "--seek-frames", "4"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and len(out["config"]["ranges"]) == 2
+    assert out["md5_verified"]["ranges"] == 2 and out["value"] > 0 and len(out["rank_ms_per_step"]) == 2
