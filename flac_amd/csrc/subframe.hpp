@@ -488,6 +488,30 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
                         longest = max(longest, tot);
                         Q -= tot;
                     }
+                } else if constexpr (variant::kSkimRawCounts) {
+                    // Two codes per 64-bit window on the hardware's unclamped leading-zero count (all ones for a zero
+                    // window) and negated lengths, as the decoder's unrolled groups do: four dependent instructions
+                    // fewer per pair than with clamped counts and positive lengths.  A lane whose streams are few
+                    // (one long multichannel stream) is bound by exactly this chain.  A code fits its window when its unary
+                    // count is at most 31 - k; the largest count of the group is tested once.
+                    const uint32_t neg_k1 = 0u - (k + 1);
+                    uint32_t qor = 0;   // largest unary count
+#pragma unroll
+                    for (int P = 0; P < (int)G / 2; ++P) {
+                        if (2 * P == (int)kRoundSteps) {
+                            br.P = 0u - Q;
+                            starved = starved || br.starved();
+                            ring_round<true>(br, rf, reads);
+                        }
+                        const uint2 w = br.peek64_ring_neg(Q);
+                        const uint32_t q1 = lead_zeros_raw(w.x);
+                        const uint32_t neg_n1 = neg_k1 - q1;
+                        const uint32_t w2 = __builtin_amdgcn_alignbit(w.x, w.y, neg_n1);   // the window n1 bits on: the shift takes -n1 mod 32 itself
+                        const uint32_t q2 = lead_zeros_raw(w2);
+                        qor = max(qor, max(q1, q2));
+                        Q += neg_n1 + (neg_k1 - q2);
+                    }
+                    longest = qor > 31u - k ? 33u : 0u;
                 } else {
                     if constexpr (variant::kSkimWide) {
                         // two codes per 64-bit window: either code may be up to 32 bits long.  The OR of the lengths

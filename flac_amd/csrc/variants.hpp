@@ -69,5 +69,11 @@ constexpr bool kSkimWide = false;        // one code per 32-bit window where two
 constexpr bool kSkimWide = true;
 #endif
 
+#ifdef FLACGPU_SKIM_CLAMPED_COUNTS
+constexpr bool kSkimRawCounts = false;   // the wide loop on clamped counts and positive lengths (the earlier loop)
+#else
+constexpr bool kSkimRawCounts = true;
+#endif
+
 }  // namespace variant
 }  // namespace flacgpu
