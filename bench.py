@@ -210,8 +210,7 @@ def lookup_traffic(tag, kernel, nfiles):
     scaled by file count.  Returns (traffic bytes or None, details dict).  Counters cannot be read from inside this
     process, so the figure comes from a rocprofv3 --pmc run of this same command at fewer files.  The write side
     (WRITE_SIZE) needs no correction.  The read side is reported three ways: raw FETCH_SIZE, the request-size split
-    (128-byte requests x 128 + 32-byte requests x 32 + the others x 64, from TCC_BUBBLE / TCC_EA0_RDREQ_32B /
-    TCC_EA0_RDREQ) when the profile has that pass,
+    (TCC_EA0_RDREQ_DRAM_32B: read requests counted in 32-byte units, whatever their size) when the profile has that pass,
     and raw x 2, the upper bound that holds if every request were a 128-byte one tallied at 64 (true for wide
     coalesced reads on gfx950).  `traffic` uses the split when present, else the raw figure."""
     import glob
@@ -225,15 +224,16 @@ def lookup_traffic(tag, kernel, nfiles):
             raw = kd["FETCH_SIZE_KiB"] * 1024.0 * scale
             wr = kd["WRITE_SIZE_KiB"] * 1024.0 * scale
             split = None
-            if "TCC_EA0_RDREQ" in kd and "TCC_EA0_RDREQ_32B" in kd and "TCC_BUBBLE" in kd:
-                # requests by size: TCC_BUBBLE counts the 128-byte ones, TCC_EA0_RDREQ_32B the 32-byte ones, the rest are 64
-                split = (kd["TCC_BUBBLE"] * 128.0 + kd["TCC_EA0_RDREQ_32B"] * 32.0
-                         + (kd["TCC_EA0_RDREQ"] - kd["TCC_BUBBLE"] - kd["TCC_EA0_RDREQ_32B"]) * 64.0) * scale
+            if "TCC_EA0_RDREQ_DRAM_32B" in kd:
+                # read requests in units of 32 bytes (a 64-byte request counts 2, a 128-byte one 4): the exact figure.
+                # (FETCH_SIZE is built from TCC_BUBBLE, the count of 128-byte requests, which reads 0 on this chip.)
+                split = kd["TCC_EA0_RDREQ_DRAM_32B"] * 32.0 * scale
             read = split if split is not None else raw
             return read + wr, {"profile": os.path.relpath(path, ROOT), "profile_commit": pmc.get("commit"),
                                "files_profiled": pmc["files"], "write_bytes": wr, "read_bytes_fetch_size_raw": raw,
                                "read_bytes_request_split": split, "read_bytes_upper_bound_x2": 2.0 * raw,
-                               "read_side_used": "request split" if split is not None else "raw FETCH_SIZE"}
+                               "read_requests": kd.get("TCC_EA0_RDREQ", 0) * scale or None,
+                               "read_side_used": "32 x TCC_EA0_RDREQ_DRAM_32B" if split is not None else "raw FETCH_SIZE"}
         except (OSError, KeyError, ValueError, TypeError):
             continue
     return None, {"note": f"no committed counter profile of {kernel} on workload {tag}"}

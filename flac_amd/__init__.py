@@ -419,6 +419,7 @@ class Decoder:
         if rc:
             raise FlacError(rc, "flacgpu_create")
         self.device = int(device)
+        self.output_format = int(output_format)
 
     def close(self):
         if self._h:
@@ -479,7 +480,9 @@ class Decoder:
         """Host buffers in, host PCM out (copies over PCIe).  audio_list: per stream the bytes from frame 0."""
         n = len(audio_list)
         arrs = [np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8)) for a in audio_list]
-        outs = [np.empty(si.pcm_bytes, dtype=np.uint8) for si in infos]   # the library fills every byte (zeros where a frame failed)
+        # the library fills every byte (zeros where a frame failed); 32-bit output takes 4 bytes per sample
+        sizes = [int(si.total_samples) * si.channels * 4 if self.output_format == OUT_S32 else si.pcm_bytes for si in infos]
+        outs = [np.empty(n, dtype=np.uint8) for n in sizes]
         bufs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
         lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
         sis = (StreamInfo * n)()

@@ -140,7 +140,10 @@ int build_streams(flacgpu_handle *h, uint64_t in_bytes, uint64_t out_bytes, cons
         d.channels = s.info.channels; d.bps = s.info.bits_per_sample;
         d.bytes_ps = h->output_format == FLACGPU_OUT_S32 ? 4 : (uint8_t)((s.info.bits_per_sample + 7) / 8);
         // planar: equal planes, each a whole number of dwords
-        if (need_out && h->output_format == FLACGPU_OUT_PLANAR) d.plane_stride = (s.out_capacity / s.info.channels) & ~(uint64_t)3;
+        if (need_out && h->output_format == FLACGPU_OUT_PLANAR) {
+            d.plane_stride = (s.out_capacity / s.info.channels) & ~(uint64_t)3;
+            if (d.plane_stride == 0) { d.plane_stride = 4; d.out_cap = 0; }   // no room for a plane: every frame is out of range
+        }
         h->h_streams[i] = d;
     }
     return FLACGPU_OK;
@@ -164,11 +167,11 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
     if ((rc = reserve(h, h->group_sum, (size_t)n_groups * 4))) return rc;
     if ((rc = reserve(h, h->group_base, (size_t)n_groups * 4))) return rc;
     if ((rc = reserve(h, h->counter, 64))) return rc;
-    if ((rc = reserve(h, h->segrec, (size_t)n_tiles * 4 * kSegSlots * 4))) return rc;
+    if ((rc = reserve(h, h->segrec, (size_t)n_tiles * kScanWaves * kSegSlots * 4))) return rc;
 
     HIP_TRY(hipMemcpyAsync(h->streams.p, h->h_streams.data(), (size_t)n * sizeof(StreamDev), hipMemcpyHostToDevice, st));
     mark(h, EV_START, st);
-    k_scan_tiles<<<n_tiles, 256, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (uint16_t *)h->mask.p,
+    k_scan_tiles<<<n_tiles, kScanThreads, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (uint16_t *)h->mask.p,
                                           (uint64_t *)h->bitmap.p, (uint32_t *)h->tile_count.p, (uint32_t *)h->segrec.p);
     mark(h, EV_SCAN, st);
     k_tile_prefix_local<<<n_groups, 1024, 0, st>>>((const uint32_t *)h->tile_count.p, (uint32_t *)h->tile_base.p, n_tiles,
@@ -596,7 +599,7 @@ constexpr size_t kNaSizes[] = {
     na_round(((kNaTiles + kPrefixGroup - 1) / kPrefixGroup) * 4),   // group_base
     na_round(64),                                     // counter
     na_round(kCrcTableEntries * 2),                   // crc_tables
-    na_round(kNaTiles * 4 * kSegSlots * 4),           // segrec
+    na_round(kNaTiles * kScanWaves * kSegSlots * 4),  // segrec
     na_round(kNaMaxCand * 8), na_round(kNaMaxCand * 8), na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 4),   // goff num info stream
     na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 4), na_round(kNaMaxCand * 2), na_round(kNaMaxCand * 4),   // len status segcrc seglen
     na_round(kNaMaxCand * 8 * 4), na_round(kNaMaxCand * 4),                                                  // subpos next

@@ -15,7 +15,7 @@
 //   k_stream_ranges candidate range of every stream.
 //   k_span_crc      CRC-16 of the bytes between consecutive candidates from the
 //                   records k_scan_tiles leaves where it cuts its running CRC-16
-//                   (every sync code, every 16 KiB).
+//                   (every sync code, and the end of every range a wave steps over).
 //   k_crc16_spans   the same by reading the bytes: one wave per span, lanes load
 //                   consecutive 16-byte vectors into wide accumulators.  For the few
 //                   spans the records cannot give, and for the encoder.
@@ -30,6 +30,7 @@
 #pragma once
 
 #include "device_types.hpp"
+#include "variants.hpp"
 
 namespace flacgpu {
 
@@ -165,9 +166,9 @@ __device__ inline void crc16_pow_table(uint16_t *pow2)
 // and for k_span_crc, which joins the scan's cut records:
 //   invpad[n]    (1025)      x^(-8 * n), the zero bytes between a cut and the end of its 1 KiB step
 //   powlo[n]     (128)       x^(8 * n)
-//   powhi[n]     (129)       x^(8 * 128 * n): x^(8 * d) = powhi[d / 128] * powlo[d % 128] for d up to 16 KiB
+//   powhi[n]     (513)       x^(8 * 128 * n): x^(8 * d) = powhi[d / 128] * powlo[d % 128] for d up to 64 KiB (a range is at most a scan tile)
 constexpr int kCrcPow2 = 0, kCrcInv = kCrcPow2 + 32, kCrcCoreEntries = kCrcInv + 16, kCrcInvPad = kCrcCoreEntries,
-              kCrcPowLo = kCrcInvPad + 1025, kCrcPowHi = kCrcPowLo + 128, kCrcTableEntries = (kCrcPowHi + 129 + 1) & ~1;
+              kCrcPowLo = kCrcInvPad + 1025, kCrcPowHi = kCrcPowLo + 128, kCrcTableEntries = (kCrcPowHi + 513 + 1) & ~1;
 
 __global__ void k_crc16_build_tables(uint16_t *t)
 {
@@ -326,16 +327,25 @@ __device__ inline void crc16_keep_head(uint32_t n, uint32_t &w0, uint32_t &w1, u
 
 // Cut records of the scan.  k_scan_tiles has every byte in registers once; it keeps the wide accumulators of the
 // CRC-16 running while it searches, and cuts the running message at every sync code it sees (validated or not) and
-// at the end of the 16 KiB a wave steps over.  A cut leaves a record: where it is, and the CRC-16 of the bytes since
+// at the end of the range a wave steps over (32 KiB).  A cut leaves a record: where it is, and the CRC-16 of the bytes since
 // the cut before it, zero-padded to the end of the cut's 1 KiB step.  The CRC-16 of a span between two candidates
 // (both are sync codes, so both are cuts) is then a few multiplications by powers of x over the records in between
 // (k_span_crc): the compressed bytes are not read a second time for it.
 //   segrec[range * kSegSlots + 0]      = number of cuts in the range (kSegOverflow: more than fit) | CRC-16 up to the range's end << 16
 //   segrec[range * kSegSlots + 1 + i]  = offset of cut i inside the range | CRC-16 up to the cut << 16
-constexpr uint32_t kSegRangeLog2 = 14, kSegRangeBytes = 1u << kSegRangeLog2;   // one wave's share of a scan tile
-constexpr uint32_t kSegSlots = 32;
+// A range ends with a cut of its own, and a cut costs about 300 vector instructions, so longer ranges are cheaper: two
+// waves per 64 KiB tile, 32 KiB each, instead of four with 16 KiB (one cut of 3.25 per 16 KiB saved in 16-bit stereo
+// with 4096-sample blocks).  One wave per tile would leave a CU with too few waves (the tile's LDS allows 13 blocks).
+constexpr uint32_t kScanWaves = variant::kScanWaves;                            // waves per scan tile
+constexpr uint32_t kScanThreads = 64 * kScanWaves;
+constexpr uint32_t kSegRangeBytes = kScanTileBytes / kScanWaves;                // one wave's share of a scan tile
+constexpr uint32_t kSegRangeLog2 = kSegRangeBytes == 65536 ? 16 : kSegRangeBytes == 32768 ? 15 : 14;
+constexpr uint32_t kSegSlots = 32 * (kSegRangeBytes / 16384);                   // the same room per byte of input whatever the range
 constexpr uint32_t kSegOverflow = 0xFFFFu;
-static_assert(kSegRangeBytes * 4 == kScanTileBytes, "a scan tile is four waves' ranges");
+static_assert((1u << kSegRangeLog2) == kSegRangeBytes && kSegRangeBytes * kScanWaves == kScanTileBytes, "a scan tile is its waves' ranges");
+constexpr uint32_t kRangeChunks = kSegRangeBytes / 1024;                        // 1 KiB wave steps per range
+// crc16_acc_merge<5> holds accumulators with up to eight steps behind them (128 + 7 bits, three multiplications by x^8 + ...: 159)
+static_assert(kRangeChunks / 4 <= 8 || kScanWaves == 1, "more steps per accumulator need the six-word merge");
 
 // ------------------------------------------------------------------ scan ---
 
@@ -374,7 +384,7 @@ __device__ inline int find_stream_in(const StreamDev *streams, uint32_t lo, uint
 }
 
 // One workgroup per 64 KiB tile.
-//   1. detect: each wave steps over its 16 KiB in 1 KiB chunks, four chunks loaded ahead.  A sync code
+//   1. detect: each wave steps over its range in 1 KiB chunks, four chunks loaded ahead.  A sync code
 //      at byte j is the 16-bit field (byte j, byte j+1) with (field & 0xFEFF) == 0xF8FF; sixteen
 //      sub-dword compares per chunk give the hit lanes of every byte position as scalar masks, so the
 //      common chunk without any sync code costs no per-lane work beyond the compares.
@@ -385,7 +395,7 @@ __device__ inline int find_stream_in(const StreamDev *streams, uint32_t lo, uint
 //   4. write-out: mask words that are not zero go to `mask16` (sparse: the rest of the array is not
 //      written and never read), `bitmap64` gets one bit per 16-byte granule ("mask16 entry is valid and
 //      not zero"), `tile_count` the number of candidates.
-__global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ in, uint64_t in_bytes,
+__global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint8_t *__restrict__ in, uint64_t in_bytes,
                                                     const StreamDev *__restrict__ streams, uint32_t n_streams,
                                                     uint16_t *__restrict__ mask16, uint64_t *__restrict__ bitmap64,
                                                     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ segrec)
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
     __shared__ uint32_t s_nhits, s_count;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s_mask[k * 256 + tid] = 0;   // consecutive lanes, consecutive banks
+    for (int k = 0; k < (int)(kScanTileBytes / 32 / kScanThreads); ++k) s_mask[k * kScanThreads + tid] = 0;   // consecutive lanes, consecutive banks
     if (tid == 0) { s_nhits = 0; s_count = 0; }
     __syncthreads();
     const uint64_t tile_base = (uint64_t)blockIdx.x * kScanTileBytes;
@@ -422,12 +432,12 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
     CrcAcc acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) crc16_acc_clear(acc[k]);
-    uint32_t *const rec = segrec + ((uint64_t)blockIdx.x * 4 + wave) * kSegSlots;
+    uint32_t *const rec = segrec + ((uint64_t)blockIdx.x * kScanWaves + wave) * kSegSlots;
     uint32_t ncuts = 0;
     // CRC-16 of everything accumulated, as if the message ended with chunk k (index modulo 4): the same in every lane
     auto wave_flush = [&](int k) {
         uint32_t q, parity;
-        crc16_acc_merge<5>(acc[k], acc[(k + 3) & 3], acc[(k + 2) & 3], acc[(k + 1) & 3], q, parity);
+        crc16_acc_merge<(kRangeChunks / 4 <= 8 ? 5 : 6)>(acc[k], acc[(k + 3) & 3], acc[(k + 2) & 3], acc[(k + 1) & 3], q, parity);
         return crc16_wave_join(q, parity);
     };
 
@@ -436,8 +446,8 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
     // offset, from the tile's first byte, of the last 16-byte vector that holds a byte of the input (the grid has no
     // tile without one)
     const uint32_t last_vec = (uint32_t)min((uint64_t)kScanTileBytes - kGranule, (in_bytes - tile_base - 1) & ~(uint64_t)(kGranule - 1));
-    for (uint32_t round = 0; round < 4; ++round) {
-        const uint32_t chunk0 = wave * 16 + round * 4;
+    for (uint32_t round = 0; round < kRangeChunks / 4; ++round) {
+        const uint32_t chunk0 = wave * kRangeChunks + round * 4;
         uint4 v[4];
         // A lane past the end of the input loads the input's last vector again instead (one 32-bit minimum per load,
         // and the address is the tile's scalar base plus a 32-bit lane offset): what such lanes see is never used,
@@ -519,39 +529,45 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint8_t *__restrict__ 
     __syncthreads();
     const uint32_t nh = s_nhits;
     if (nh <= kHitCap) {
-        for (uint32_t i = tid; i < nh; i += 256) validate(s_hits[i]);
+        for (uint32_t i = tid; i < nh; i += kScanThreads) validate(s_hits[i]);
     } else {
         // more sync codes than the list holds (not audio: a crafted or degenerate input): every thread
-        // tests the 256 byte positions it owns one by one
-        for (uint32_t i = 0; i < 256; ++i) {
-            const uint32_t off = tid * 256 + i;
+        // tests the byte positions it owns one by one
+        constexpr uint32_t kOwn = kScanTileBytes / kScanThreads;
+        for (uint32_t i = 0; i < kOwn; ++i) {
+            const uint32_t off = tid * kOwn + i;
             const uint64_t g = tile_base + off;
             if (g + 1 < in_bytes && in[g] == 0xFF && (in[g + 1] & 0xFE) == 0xF8) validate(off);
         }
     }
     __syncthreads();
 
-    // thread t owns granules 16t .. 16t+15 = mask words 8t .. 8t+7
-    uint32_t nz = 0, cnt = 0;
-    const uint64_t granule0 = (uint64_t)blockIdx.x * kTileGranules + tid * 16;
-    // (two 16-byte reads: word by word, lanes eight words apart would share four of the 32 banks)
-    const uint4 m_lo = reinterpret_cast<const uint4 *>(s_mask)[tid * 2], m_hi = reinterpret_cast<const uint4 *>(s_mask)[tid * 2 + 1];
-    const uint32_t m_own[8] = {m_lo.x, m_lo.y, m_lo.z, m_lo.w, m_hi.x, m_hi.y, m_hi.z, m_hi.w};
+    // A virtual thread v of 256 owns granules 16v .. 16v+15 = mask words 8v .. 8v+7; a thread plays 256 / kScanThreads of them.
+    uint32_t cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t x = m_own[k];
-        if (x) {
-            cnt += __builtin_popcount(x);
-            if (x & 0xFFFFu) { mask16[granule0 + 2 * k] = (uint16_t)x; nz |= 1u << (2 * k); }
-            if (x >> 16) { mask16[granule0 + 2 * k + 1] = (uint16_t)(x >> 16); nz |= 2u << (2 * k); }
+    for (uint32_t rep = 0; rep < 256 / kScanThreads; ++rep) {
+        const uint32_t vt = rep * kScanThreads + tid;
+        uint32_t nz = 0;
+        const uint64_t granule0 = (uint64_t)blockIdx.x * kTileGranules + vt * 16;
+        // (two 16-byte reads: word by word, lanes eight words apart would share four of the 32 banks)
+        const uint4 m_lo = reinterpret_cast<const uint4 *>(s_mask)[vt * 2], m_hi = reinterpret_cast<const uint4 *>(s_mask)[vt * 2 + 1];
+        const uint32_t m_own[8] = {m_lo.x, m_lo.y, m_lo.z, m_lo.w, m_hi.x, m_hi.y, m_hi.z, m_hi.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t x = m_own[k];
+            if (x) {
+                cnt += __builtin_popcount(x);
+                if (x & 0xFFFFu) { mask16[granule0 + 2 * k] = (uint16_t)x; nz |= 1u << (2 * k); }
+                if (x >> 16) { mask16[granule0 + 2 * k + 1] = (uint16_t)(x >> 16); nz |= 2u << (2 * k); }
+            }
         }
+        // four virtual threads' 16 flags make one 64-bit bitmap word (1 KiB of input); they are four neighbouring lanes
+        const uint32_t base = lane & ~3u;
+        const uint32_t n0 = (uint32_t)__shfl((int)nz, (int)base), n1 = (uint32_t)__shfl((int)nz, (int)base + 1),
+                       n2 = (uint32_t)__shfl((int)nz, (int)base + 2), n3 = (uint32_t)__shfl((int)nz, (int)base + 3);
+        if ((lane & 3) == 0)
+            bitmap64[(uint64_t)blockIdx.x * kTileChunks + (vt >> 2)] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32);
     }
-    // four threads' 16 flags make one 64-bit bitmap word (1 KiB of input)
-    const uint32_t base = lane & ~3u;
-    const uint32_t n0 = (uint32_t)__shfl((int)nz, (int)base), n1 = (uint32_t)__shfl((int)nz, (int)base + 1),
-                   n2 = (uint32_t)__shfl((int)nz, (int)base + 2), n3 = (uint32_t)__shfl((int)nz, (int)base + 3);
-    if ((lane & 3) == 0)
-        bitmap64[(uint64_t)blockIdx.x * kTileChunks + (tid >> 2)] = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32);
     if (cnt) atomicAdd(&s_count, cnt);
     __syncthreads();
     if (tid == 0) tile_count[blockIdx.x] = s_count;

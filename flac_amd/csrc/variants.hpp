@@ -69,6 +69,11 @@ constexpr bool kSkimWide = false;        // one code per 32-bit window where two
 constexpr bool kSkimWide = true;
 #endif
 
+#ifdef FLACGPU_SCAN_WAVES
+constexpr uint32_t kScanWaves = FLACGPU_SCAN_WAVES;
+#else
+constexpr uint32_t kScanWaves = 2;       // waves per 64 KiB scan tile: each steps over 32 KiB and ends it with one cut
+#endif
 #ifdef FLACGPU_SKIM_CLAMPED_COUNTS
 constexpr bool kSkimRawCounts = false;   // the wide loop on clamped counts and positive lengths (the earlier loop)
 #else

@@ -298,7 +298,7 @@ typedef struct flacgpu_timing {
     uint32_t decode_classes;  /* decode kernel classes the batch used: bit (taps == 32) + 2 * arithmetic
                                  (0 = 24-bit multiplies, 1 = 32-bit, 2 = 64-bit sums, 3 = 16-bit pairs) */
     uint32_t crc16_reread_spans;  /* candidate spans whose CRC-16 needed a second read of their bytes (the last
-                                     span of every stream, and spans through 16 KiB of input with more than 31
+                                     span of every stream, and spans through 32 KiB of input with more than 63
                                      sync codes); every other span's CRC-16 comes out of the scan's single pass */
     uint32_t launches;        /* kernels the call launched (streams are grouped by channel count and output
                                  sample size: one skim and one set of decode launches per distinct shape) */
@@ -332,7 +332,8 @@ int flacgpu_scan_frames(flacgpu_handle *h, const void *d_in, uint64_t in_bytes,
  * the statuses include what the subframe decoder found (FLACGPU_FRAME_BAD_SUBFRAME, _TRUNCATED, _LENGTH,
  * _RANGE), so a caller who sees frames_ok < frames learns which frames failed and why.  frames: host array
  * of cap entries (NULL with cap 0 just counts); FLACGPU_ERR_CAPACITY when cap is too small, with *n_frames
- * set to the number needed. */
+ * set to the number needed.  After flacgpu_decode_batch (host buffers, decoded in chunks of streams) the table
+ * is that of the last chunk; flacgpu_frame.stream then counts from that chunk's first stream. */
 int flacgpu_get_frames(flacgpu_handle *h, flacgpu_frame *frames, uint64_t cap, uint64_t *n_frames);
 
 /* Decode a device-resident batch: frame scan, Rice/LPC reconstruction,

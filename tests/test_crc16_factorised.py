@@ -198,35 +198,39 @@ def _xpow8(n):                      # x^(8 n) modulo P
     return r
 
 
+RANGE_LOG2 = 15   # kSegRangeLog2 of frame_scan.hpp
+RANGE = 1 << RANGE_LOG2
+
+
 def _scan_records(data, cuts):
-    """What the scan leaves for one input: per 16 KiB range the cuts inside it (offset in the range, CRC-16 of the
+    """What the scan leaves for one input: per range (RANGE bytes, one wave's share of a scan tile) the cuts inside it (offset in the range, CRC-16 of the
     bytes since the cut before or the range's start, zero-padded to the end of the cut's 1 KiB step) and the CRC-16
     from the last cut to the range's end."""
     ranges = []
-    for base in range(0, len(data), 16384):
+    for base in range(0, len(data), RANGE):
         last, recs = base, []
-        for p in sorted(c for c in cuts if base <= c < base + 16384):
+        for p in sorted(c for c in cuts if base <= c < base + RANGE):
             pad = 1024 - (p & 1023)
             recs.append((p - base, oracle.crc16(data[last:p] + bytes(pad))))
             last = p
-        ranges.append((recs, oracle.crc16(data[last:base + 16384])))
+        ranges.append((recs, oracle.crc16(data[last:base + RANGE])))
     return ranges
 
 
 def _span_crc(ranges, a, e):
     """k_span_crc's walk: CRC-16 of [a, e), both of them cuts, from the records."""
-    rng_i = a >> 14
+    rng_i = a >> RANGE_LOG2
     recs, end_crc = ranges[rng_i]
-    i = [off for off, _ in recs].index(a & 16383)
+    i = [off for off, _ in recs].index(a & (RANGE - 1))
     crc, pos = 0, a
     while pos < e:
         if i + 1 < len(recs):
             i += 1
             off, v = recs[i]
-            b = (rng_i << 14) + off
+            b = (rng_i << RANGE_LOG2) + off
             v = _gf_mulmod(v, _xpow8(32767 - (1024 - (off & 1023))))      # x has order 32767: takes the padding out
         else:
-            b, v = (rng_i + 1) << 14, end_crc
+            b, v = (rng_i + 1) << RANGE_LOG2, end_crc
             if b < e:
                 rng_i += 1
                 recs, end_crc = ranges[rng_i]
@@ -239,8 +243,8 @@ def _span_crc(ranges, a, e):
 
 def test_record_walk_equals_crc16():
     rng = np.random.default_rng(19)
-    data = bytes(rng.integers(0, 256, size=5 * 16384).astype(np.uint8))
-    cuts = sorted(set(int(c) for c in rng.integers(0, len(data), size=40)) | {0, 1023, 1024, 16384, 3 * 16384 - 1, 3 * 16384})
+    data = bytes(rng.integers(0, 256, size=5 * RANGE).astype(np.uint8))
+    cuts = sorted(set(int(c) for c in rng.integers(0, len(data), size=40)) | {0, 1023, 1024, RANGE, 3 * RANGE - 1, 3 * RANGE})
     ranges = _scan_records(data, cuts)
     for n, a in enumerate(cuts):
         for e in cuts[n + 1: n + 12]:

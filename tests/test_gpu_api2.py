@@ -126,6 +126,11 @@ def test_s32_output():
         got = o.view(np.int32).reshape(-1, si.channels)
         assert np.array_equal(got, _samples(si, want)), name
         assert r.pcm_bytes == int(si.total_samples) * si.channels * 4
+    # the host-buffer entry point with the same option
+    houts, hres = dec.decode_batch([split_file(f)[1] for _, f in files[:5]], infos[:5])
+    for (name, f), o, si in zip(files[:5], houts, infos[:5]):
+        want, _ = oracle_decode(si, split_file(f)[1])
+        assert np.array_equal(o.view(np.int32).reshape(-1, si.channels), _samples(si, want)), name
     dec.close()
 
 

@@ -493,11 +493,11 @@ def _decode_arena(decoder, files, gap, gap_fill):
 def test_crc16_comes_out_of_the_scan(decoder):
     """The frame CRC-16 is accumulated by the scan kernel in its single pass over the input and cut at every sync
     code; only the last span of a stream (it ends at the stream's end, not at a sync code) is read a second time.
-    When 16 KiB of input hold more sync codes than a record has slots (here: the bytes between the streams are
-    nothing but sync codes), the spans through them are read again instead.  Either way every frame's CRC-16
-    must come out as the oracle's does, for spans of one byte of payload up to spans over several 16 KiB ranges."""
+    When a range of the scan (32 KiB of input) holds more sync codes than its record has slots (here: the bytes between
+    the streams are nothing but sync codes), the spans through it are read again instead.  Either way every frame's CRC-16
+    must come out as the oracle's does, for spans of one byte of payload up to spans over several ranges."""
     big = [(2, 16, 30000, 1152), (8, 24, 40000, 16384), (2, 16, 4096 * 9 + 5, 4096), (1, 16, 20000, 4608)]
-    small = [(1, 16, 9000, 192), (2, 8, 700, 16)]       # dozens of frames in 16 KiB: more cuts than a record holds
+    small = [(1, 16, 40000, 192), (2, 8, 2500, 16)]     # hundreds of frames in one 32 KiB range: more cuts than a record holds
     files = []
     for i, (ch, bps, n, bs) in enumerate(big + small):
         x = synth.pcm(1300 + i, n, ch, bps, 44100, bs)
