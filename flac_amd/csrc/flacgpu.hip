@@ -171,8 +171,11 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
 
     HIP_TRY(hipMemcpyAsync(h->streams.p, h->h_streams.data(), (size_t)n * sizeof(StreamDev), hipMemcpyHostToDevice, st));
     mark(h, EV_START, st);
+    // tile_base is free until the prefix kernels write it: it holds every tile's first stream for the scan
+    k_tile_streams<<<(n_tiles + 255) / 256, 256, 0, st>>>((const StreamDev *)h->streams.p, n, n_tiles, (uint32_t *)h->tile_base.p);
     k_scan_tiles<<<n_tiles, kScanThreads, 0, st>>>(d_in, in_bytes, (const StreamDev *)h->streams.p, n, (uint16_t *)h->mask.p,
-                                          (uint64_t *)h->bitmap.p, (uint32_t *)h->tile_count.p, (uint32_t *)h->segrec.p);
+                                          (uint64_t *)h->bitmap.p, (uint32_t *)h->tile_count.p, (uint32_t *)h->segrec.p,
+                                          (const uint32_t *)h->tile_base.p);
     mark(h, EV_SCAN, st);
     k_tile_prefix_local<<<n_groups, 1024, 0, st>>>((const uint32_t *)h->tile_count.p, (uint32_t *)h->tile_base.p, n_tiles,
                                                    (uint32_t *)h->group_sum.p);
@@ -209,7 +212,7 @@ int run_scan(flacgpu_handle *h, const uint8_t *d_in, uint64_t in_bytes, uint32_t
         k_resolve_walk<<<(n + 3) / 4, 256, 0, st>>>((const StreamDev *)h->streams.p, n, c);
     }
     mark(h, EV_RESOLVE, st);
-    h->launches = n_cand ? 10 : 4;   // scan, two prefix kernels, stream ranges; with candidates: compact, fill, two CRC-16, two resolve
+    h->launches = n_cand ? 11 : 5;   // tile streams, scan, two prefix kernels, stream ranges; with candidates: compact, fill, two CRC-16, two resolve
     HIP_TRY(hipMemcpyAsync(h->h_streams.data(), h->streams.p, (size_t)n * sizeof(StreamDev), hipMemcpyDeviceToHost, st));
     h->n_reread = 0;
     if (n_cand) HIP_TRY(hipMemcpyAsync(&h->n_reread, (uint32_t *)h->counter.p + 1, 4, hipMemcpyDeviceToHost, st));
