@@ -253,6 +253,9 @@ def lookup_valu(tag, kernel):
     return None, None
 
 
+NOMINAL_CLOCK_MHZ = 2400.0   # MI355X peak engine clock
+
+
 def device_description(torch, dev):
     prop = torch.cuda.get_device_properties(dev)
     return {"name": prop.name, "arch": getattr(prop, "gcnArchName", None), "compute_units": prop.multi_processor_count,
@@ -265,15 +268,16 @@ def valu_issue(tag, kernel, values, seconds, device):
     sample step (one wave instruction covers one sample of 64 subframes) from the committed SQ profile of this
     workload, times the launch's sample steps, over issue_peak = CUs x 4 SIMDs x clock / 4 cycles per instruction."""
     per_step, src = lookup_valu(tag, kernel)
-    if per_step is None or seconds <= 0 or not device.get("clock_MHz"):
+    if per_step is None or seconds <= 0:
         return None
-    clock = device["clock_MHz"] * 1e6
+    clock_mhz = device.get("clock_MHz") or NOMINAL_CLOCK_MHZ     # the runtime does not always report one
+    clock = clock_mhz * 1e6
     peak = device["compute_units"] * 4 * clock / 4.0
     rate = per_step * (values / 64.0) / seconds
     return {"insts_per_sample_step": per_step, "source": src, "sample_steps_per_launch": values / 64.0,
-            "issue_peak_per_s": peak, "frac": rate / peak, "clock_MHz_nominal": device["clock_MHz"],
+            "issue_peak_per_s": peak, "frac": rate / peak, "clock_MHz_nominal": clock_mhz,
             # the clock at which the launch's instructions alone would fill every issue slot of its duration
-            "clock_MHz_if_all_slots_filled": device["clock_MHz"] * rate / peak}
+            "clock_MHz_if_all_slots_filled": clock_mhz * rate / peak}
 
 
 def host_description():

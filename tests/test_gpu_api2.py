@@ -243,3 +243,29 @@ def test_two_ranks_share_one_stream_on_one_gpu(tmp_path):
     """The frame-range path at world size 2 with both ranks on this GPU (rows and the chained MD5 over gloo)."""
     from test_sharding_gloo import _run, check_range_run
     check_range_run(_run(2, str(tmp_path / "g2.json"), 29621, "_range_worker.py", "gpu"), 2)
+
+
+def test_argument_errors_of_the_new_options(decoder):
+    import ctypes
+    import torch
+    # an output format the library does not know
+    with pytest.raises(flac_amd.FlacError) as e:
+        flac_amd.Decoder(0, output_format=7)
+    assert e.value.status == 1
+    # a frame array that is too small: the status says so and the count is what is needed
+    f = [fl for name, fl in _shape_files() if name == "stereo16-lpc12"][0]
+    _, res, _ = gpu_batch(decoder, [f])
+    lib, h = flac_amd.lib(), decoder._h
+    n = ctypes.c_uint64()
+    few = (flac_amd.Frame * 2)()
+    assert lib.flacgpu_get_frames(h, few, 2, ctypes.byref(n)) == flac_amd.ERR_CAPACITY and n.value == res[0].frames > 2
+    assert [fr.status for fr in few] == [0, 0] and few[1].offset > few[0].offset          # what fits is filled
+    assert lib.flacgpu_get_frames(h, None, 0, ctypes.byref(n)) == 0 and n.value == res[0].frames
+    # a sample_base beyond the stream
+    si, audio = split_file(f)
+    d_in = torch.frombuffer(bytearray(audio) + bytearray(64), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(si.pcm_bytes + 64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(flac_amd.FlacError) as e:
+        decoder.decode_batch_device(d_in, len(audio), d_out, si.pcm_bytes, decoder.make_streams([(0, len(audio), 0, si.pcm_bytes, si, int(si.total_samples) + 1)]))
+    assert e.value.status == 1 and "sample_base" in str(e.value)
+    assert flac_amd.lib().flacgpu_api_version() == flac_amd.API_VERSION == 2
