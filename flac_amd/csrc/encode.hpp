@@ -826,12 +826,18 @@ __device__ inline float row_butterfly_f32(float v)
     return v;
 }
 
-template <int NT>
+// DIRECT: every estimated stream has 16-bit samples.  A lane then loads its run of 16 stereo samples and the four before it
+// straight from the PCM (five 16-byte loads of whole (left, right) words, five of the window) instead of loading samples a
+// workgroup apart and passing them through LDS to get runs: the same values in the same registers, no LDS for the samples
+// and none requested at launch, so more workgroups fit a CU.
+struct __attribute__((packed, aligned(4))) EncDwords4 { uint32_t a, b, c, d; };
+
+template <int NT, bool DIRECT>
 __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
                                                  uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
                                                  const float *__restrict__ windows, uint32_t pair_base, uint32_t pair_end)
 {
-    extern __shared__ __align__(16) int32_t xs[];   // two blocks of enc_lds_words(NT): w*l and w*r, see lds_pos
+    extern __shared__ __align__(16) int32_t xs[];   // !DIRECT: two blocks of enc_lds_words(NT): w*l and w*r, see lds_pos
     float *xl = reinterpret_cast<float *>(xs), *xr = xl + enc_lds_words(NT);
     __shared__ PickShared<NT> S;
     const uint32_t t = threadIdx.x, lane = t & 63;
@@ -847,7 +853,7 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
     const int B = st.bytes_ps;
     const uint8_t *src = pcm + st.in_off + (uint64_t)f * o.blocksize * (uint32_t)(2 * B);
     const float *win = windows + (last ? st.win_off_tail : st.win_off);
-    {
+    if constexpr (!DIRECT) {
         int32_t l[kRun], r[kRun];
         load_block_lr<NT>(src, bs, B, l, r);
 #pragma unroll
@@ -859,13 +865,43 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
             xr[at] = i < bs ? (float)r[j] * w : 0.0f;
         }
         if (t < lds_lane_base(0)) { xl[t] = 0.0f; xr[t] = 0.0f; }
+        __syncthreads();
     }
-    __syncthreads();
     {
         const uint32_t lbase = lds_lane_base(t);
-        float wl[4 + kRun], wr[4 + kRun];
+        float wl[4 + kRun], wr[4 + kRun];   // the windowed samples i0 - 4 .. i0 + 15 of the lane's run (zero outside the block)
+        if constexpr (DIRECT) {
+            const uint32_t i0 = t * kRun;
+            if (i0 >= 4 && i0 + kRun <= bs) {
+                const EncDwords4 *ps = reinterpret_cast<const EncDwords4 *>(src + (size_t)(i0 - 4) * 4);
+                const float4 *pw = reinterpret_cast<const float4 *>(win + (i0 - 4));   // window tables start on 16-byte boundaries
 #pragma unroll
-        for (int m = 0; m < 4 + kRun; ++m) { wl[m] = xl[lbase + lds_rel(m - 4)]; wr[m] = xr[lbase + lds_rel(m - 4)]; }
+                for (int q = 0; q < (4 + kRun) / 4; ++q) {
+                    const EncDwords4 v = ps[q];
+                    const float4 w = pw[q];
+                    const uint32_t lr[4] = {v.a, v.b, v.c, v.d};
+                    const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        wl[4 * q + e] = (float)((int32_t)(lr[e] << 16) >> 16) * ww[e];
+                        wr[4 * q + e] = (float)((int32_t)lr[e] >> 16) * ww[e];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4 + kRun; ++m) {
+                    const int32_t i = (int32_t)i0 + m - 4;
+                    const bool in = i >= 0 && (uint32_t)i < bs;
+                    const uint32_t lr = *reinterpret_cast<const uint32_t *>(src + (size_t)(in ? i : 0) * 4);
+                    const float w = win[in ? i : 0];
+                    wl[m] = in ? (float)((int32_t)(lr << 16) >> 16) * w : 0.0f;
+                    wr[m] = in ? (float)((int32_t)lr >> 16) * w : 0.0f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4 + kRun; ++m) { wl[m] = xl[lbase + lds_rel(m - 4)]; wr[m] = xr[lbase + lds_rel(m - 4)]; }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float x[4 + kRun], acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};

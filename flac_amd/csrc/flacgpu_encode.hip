@@ -50,15 +50,16 @@ int encode_init(flacgpu_handle *h)
 template <int M, int NT>
 int launch_analysis(flacgpu_handle *h, uint32_t, size_t lds, hipStream_t st, const uint8_t *pcm, const EncStreamDev *s,
                     uint32_t n, const uint32_t *hints, const EncOptsDev &o, const float *win, uint8_t *stats, uint8_t *plans,
-                    bool timing, bool pick)
+                    bool timing, bool pick, bool pick_direct)
 {
     if (pick) {
         // channel pair of every frame of the streams that asked for the estimate, before any candidate is analysed
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_pick<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_pick<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
         const uint32_t pairs = o.total_units / 2, pchunk = (0xF0000000u / NT) & ~7u;
         for (uint32_t b = 0; b < pairs; b += pchunk) {
             const uint32_t e = pairs - b < pchunk ? pairs : b + pchunk;
-            k_enc_pick<NT><<<(e - b + 7) / 8 * 8, NT, 2 * lds, st>>>(pcm, s, n, hints, o, win, b, e);
+            if (pick_direct) k_enc_pick<NT, true><<<(e - b + 7) / 8 * 8, NT, 0, st>>>(pcm, s, n, hints, o, win, b, e);   // 16-bit samples only: no LDS staging
+            else k_enc_pick<NT, false><<<(e - b + 7) / 8 * 8, NT, 2 * lds, st>>>(pcm, s, n, hints, o, win, b, e);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -174,7 +175,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     };
     uint64_t frames = 0, units = 0, pack_units = 0, in_total = 0;
     uint32_t max_bps = 0;
-    bool any_estimated = false;
+    bool any_estimated = false, pick_direct = true;   // pick_direct: every stream that asks for the estimate has 16-bit samples
     for (uint32_t i = 0; i < n_streams; ++i) {
         const flacgpu_pcm_stream &s = streams[i];
         if (s.channels < 1 || s.channels > 8 || s.bits_per_sample < 4 || s.bits_per_sample > 24)
@@ -202,6 +203,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
                  : opts->stereo_mode == FLACGPU_STEREO_ESTIMATE ? kPairEstimated : opts->stereo_mode;
         d.ncand = s.channels == 2 ? (d.pair == kPairNone ? 4 : 2) : s.channels;
         any_estimated |= d.pair == kPairEstimated;
+        if (d.pair == kPairEstimated && bytes_ps != 2) pick_direct = false;
         d.win_off = window_of(B);
         d.win_off_tail = d.tail_bs ? window_of(d.tail_bs) : d.win_off;
         d.meta_len = 42 + (uint32_t)flacgpu_seektable_bytes(s.total_samples, B, opts->seektable_interval);
@@ -276,10 +278,10 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     uint8_t *plans = (uint8_t *)h->e_plans.p, *stats = (uint8_t *)h->e_stats.p;
     FrameRec *fr = (FrameRec *)h->e_frames.p;
     if (units) {
-        if (M == 12 && NT == 256) rc = launch_analysis<12, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated);
-        else if (M == 32 && NT == 256) rc = launch_analysis<32, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated);
-        else if (M == 12) rc = launch_analysis<12, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated);
-        else rc = launch_analysis<32, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated);
+        if (M == 12 && NT == 256) rc = launch_analysis<12, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated, pick_direct);
+        else if (M == 32 && NT == 256) rc = launch_analysis<32, 256>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated, pick_direct);
+        else if (M == 12) rc = launch_analysis<12, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated, pick_direct);
+        else rc = launch_analysis<32, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated, pick_direct);
         if (rc) return rc;
     } else if (timing) {
         HIP_TRY(hipEventRecord(h->eev[EE_STATS], st)); HIP_TRY(hipEventRecord(h->eev[EE_DESIGN], st)); HIP_TRY(hipEventRecord(h->eev[EE_CHOOSE], st));
