@@ -436,6 +436,20 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint8_t *__re
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (streams[mid].in_off < tile_end) lo = mid + 1; else hi = mid; }
         s_hi = lo;
     }
+    // What bytes 2 and 3 of a frame header can be here, as bit tables indexed by the code (parse_frame_header's tests on
+    // them): any stream's when the tile has bytes of several streams, else that one stream's channel count, sample
+    // size and largest block.  A sync code whose next bytes fail them is no candidate, and is dropped before it costs a cut.
+    uint32_t ok_ca = 0x07FFu, ok_ss = 0xF7u, ok_bs = 0xFFFEu;
+    if (s_hi - s_lo == 1) {
+        const uint32_t channels = streams[s_lo].channels, bps = streams[s_lo].bps, max_bs = streams[s_lo].max_bs;
+        ok_ca = channels == 2 ? 0x0702u : (1u << (channels - 1)) & 0xFFu;
+        ok_ss = 1u | (bps == 8 ? 2u : bps == 12 ? 4u : bps == 16 ? 16u : bps == 20 ? 32u : bps == 24 ? 64u : bps == 32 ? 128u : 0u);
+        ok_bs = 0x00C0u;   // codes 6 and 7: the size follows the header's number
+        for (uint32_t c = 1; c < 16; ++c) {
+            const uint32_t bs = c == 1 ? 192u : c <= 5 ? 576u << (c - 2) : 256u << (c - 8);
+            if (c != 6 && c != 7 && bs <= max_bs) ok_bs |= 1u << c;
+        }
+    }
     auto validate = [&](uint32_t off) {
         const uint64_t g = tile_base + off;
         const int si = find_stream_in(streams, s_lo, s_hi, g);
@@ -475,12 +489,15 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint8_t *__re
             v[k] = *reinterpret_cast<const uint4 *>(tile_in + off);
         }
         const uint64_t g_after = tile_base + (uint64_t)(chunk0 + 4) * kChunkBytes;
-        const uint32_t byte_after = g_after < in_bytes ? in[g_after] : 0u;
+        // the four bytes after the round's last chunk (its last lane's sync test needs one, the header test three more)
+        uint32_t word_after = 0;
+        if (g_after + 4 <= in_bytes) word_after = *reinterpret_cast<const uint32_t *>(in + g_after);
+        else for (uint32_t i = 0; g_after + i < in_bytes; ++i) word_after |= (uint32_t)in[g_after + i] << (8 * i);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             // first byte of the granule that follows this lane's
             uint32_t nb = crc16_dpp<0x130>(v[k].x);   // wave_shl:1, lane l reads lane l + 1
-            const uint32_t wrap = k < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k < 3 ? k + 1 : 3].x) : byte_after;
+            const uint32_t wrap = k < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k < 3 ? k + 1 : 3].x) : word_after;
             if (lane == 63) nb = wrap;
             const uint32_t w[5] = {v[k].x, v[k].y, v[k].z, v[k].w, nb};
             uint64_t m[16];
@@ -496,6 +513,25 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint8_t *__re
             uint64_t any = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) any |= m[j];
+            // The chunk joins its accumulator whole; the rare chunk with a sync code takes its bytes out again below and
+            // adds them piece by piece (one path through the common case: a branch with the step on one side and the cuts
+            // on the other made the compiler copy the other accumulators' registers on the common side).
+            crc16_acc_step(acc[k], v[k]);
+            if (any) {
+                // Most sync codes are chance (one per 32 KiB of audio): keep those whose bytes 2 .. 4 can begin a header.
+                any = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (m[j]) {   // the same for the whole wave
+                        const uint32_t b2 = (w[(j + 2) >> 2] >> (8 * ((j + 2) & 3))) & 0xFFu, b3 = (w[(j + 3) >> 2] >> (8 * ((j + 3) & 3))) & 0xFFu,
+                                       b4 = (w[(j + 4) >> 2] >> (8 * ((j + 4) & 3))) & 0xFFu;
+                        const uint32_t codes = (ok_bs >> (b2 >> 4)) & (ok_ca >> (b3 >> 4)) & (ok_ss >> ((b3 >> 1) & 7u)) & ~b3 & 1u;
+                        const bool plausible = codes != 0 && (b2 & 15u) != 15u && b4 - 0x80u >= 0x40u && b4 != 0xFFu;
+                        m[j] &= __ballot(plausible);
+                    }
+                    any |= m[j];
+                }
+            }
             if (any) {
                 uint32_t hits = 0;
 #pragma unroll
@@ -513,9 +549,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint8_t *__re
                 }
                 // cut the running CRC-16 at every hit, in stream order: the bytes of this chunk before the hit end a
                 // message, the rest begins the next one
-                crc16_acc_step(acc[k], uint4{0u, 0u, 0u, 0u});
                 uint32_t c0 = __builtin_bswap32(v[k].x), c1 = __builtin_bswap32(v[k].y), c2 = __builtin_bswap32(v[k].z),
                          c3 = __builtin_bswap32(v[k].w);   // the chunk's bytes not yet added, as message words
+                acc[k].w[3] ^= c0; acc[k].w[2] ^= c1; acc[k].w[1] ^= c2; acc[k].w[0] ^= c3;   // (the step above added them all)
                 for (uint64_t hl = __ballot(my_hits != 0); hl; hl &= hl - 1) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(hl);
                     for (uint32_t hb = (uint32_t)__builtin_amdgcn_readlane((int)my_hits, (int)l); hb; hb &= hb - 1) {
@@ -534,8 +570,6 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint8_t *__re
                     }
                 }
                 acc[k].w[3] ^= c0; acc[k].w[2] ^= c1; acc[k].w[1] ^= c2; acc[k].w[0] ^= c3;
-            } else {
-                crc16_acc_step(acc[k], v[k]);
             }
         }
     }

@@ -493,8 +493,9 @@ def _decode_arena(decoder, files, gap, gap_fill):
 def test_crc16_comes_out_of_the_scan(decoder):
     """The frame CRC-16 is accumulated by the scan kernel in its single pass over the input and cut at every sync
     code; only the last span of a stream (it ends at the stream's end, not at a sync code) is read a second time.
-    When a range of the scan (32 KiB of input) holds more sync codes than its record has slots (here: the bytes between
-    the streams are nothing but sync codes), the spans through it are read again instead.  Either way every frame's CRC-16
+    Sync codes whose next three bytes cannot belong to a header of the stream are not cut at (a fill of bare sync codes
+    costs nothing).  When a range of the scan (32 KiB of input) holds more cuts than its record has slots (here: the bytes
+    between the streams are nothing but plausible header starts), the spans through it are read again instead.  Either way every frame's CRC-16
     must come out as the oracle's does, for spans of one byte of payload up to spans over several ranges."""
     big = [(2, 16, 30000, 1152), (8, 24, 40000, 16384), (2, 16, 4096 * 9 + 5, 4096), (1, 16, 20000, 4608)]
     small = [(1, 16, 40000, 192), (2, 8, 2500, 16)]     # hundreds of frames in one 32 KiB range: more cuts than a record holds
@@ -504,8 +505,10 @@ def test_crc16_comes_out_of_the_scan(decoder):
         f, _ = synth.encode(x, bps, 44100, synth.options(bs, 8))
         files.append(bytes(f))
     expect = [oracle_decode(*split_file(f)) for f in files]
-    for count, gap_fill, overflow in ((len(big), b"\x00", False), (len(big), b"\xff\xf8", True),
-                                      (len(big), b"\xff\xf9\x00", True), (len(files), b"\x00", True)):
+    # bytes that pass for the start of a 16-bit stereo header (block size code 1, sample rate code 9, left/side, number 0)
+    hdr_like = b"\xff\xf8\x19\x18\x00"
+    for count, gap_fill, overflow in ((len(big), b"\x00", False), (len(big), b"\xff\xf8", False), (len(big), hdr_like, True),
+                                      (len(big), b"\xff\xf9\x19\x18\x00\x00", True), (len(files), b"\x00", True)):
         pcms, res = _decode_arena(decoder, files[:count], 4096, gap_fill)
         for p, r, (want, ost) in zip(pcms, res, expect):
             assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples)
@@ -515,3 +518,39 @@ def test_crc16_comes_out_of_the_scan(decoder):
             assert reread > count
         else:
             assert 0 < reread <= count
+
+
+def test_sync_code_at_the_end_of_a_scan_step(decoder):
+    """A frame whose sync code sits in the last bytes before a boundary of the scan (the 16 bytes of a lane, the 1 KiB of a
+    wave step, the 4 KiB a wave loads at once, the 32 KiB range of a wave, the 64 KiB tile): the bytes that follow it
+    belong to the next lane, step or tile, and the scan reads the header's first bytes across that boundary before
+    it accepts the sync code.  Every stream must come out complete, its first frame included."""
+    import torch
+    specs = [(2, 16, 3000, 1152), (1, 8, 2000, 576), (8, 24, 2000, 1024), (3, 12, 2500, 1000)]
+    files = []
+    for i, (ch, bps, n, bs) in enumerate(specs):
+        x = synth.pcm(1700 + i, n, ch, bps, 44100, bs)
+        f, _ = synth.encode(x, bps, 44100, synth.options(bs, 8))
+        files.append(bytes(f))
+    parts = [split_file(f) for f in files]
+    expect = [oracle_decode(si, a) for si, a in parts]
+    places = [(b, d) for b in (16, 1024, 4096, 32768, 65536) for d in (1, 2, 3, 4, 5)]
+    span = 3 * 65536
+    assert all(len(a) < 65536 for _, a in parts)
+    host = np.zeros(span * len(places) * len(parts) + 65536, dtype=np.uint8)
+    items, out_pos = [], 0
+    for pi, (b, d) in enumerate(places):
+        for fi, (si, a) in enumerate(parts):
+            off = (pi * len(parts) + fi) * span + 65536 + b - d
+            host[off: off + len(a)] = np.frombuffer(a, dtype=np.uint8)
+            items.append((off, len(a), out_pos, si.pcm_bytes, si, fi))
+            out_pos += (si.pcm_bytes + 63) // 64 * 64
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.zeros(out_pos, dtype=torch.uint8, device="cuda")
+    res = decoder.decode_batch_device(d_in, host.size, d_out, out_pos, decoder.make_streams(it[:5] for it in items))
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for (off, n, o, nb, si, fi), r, (b, d) in zip(items, res, (pl for pl in places for _ in parts)):
+        want, ost = expect[fi]
+        assert (r.frames, r.frames_ok, r.samples) == (ost.frames, ost.frames_ok, ost.samples), (b, d, specs[fi])
+        assert np.array_equal(out[o: o + nb], want), (b, d, specs[fi])
