@@ -571,7 +571,7 @@ __device__ inline UnitInfo unit_info(const uint8_t *pcm, const EncStreamDev *str
 
 template <int NT>
 struct StatsShared {
-    uint64_t e[5];                   // fixed-predictor error sums
+    uint64_t e[5][16];               // fixed-predictor error sums, spread over 16 slots by lane (integer sums: any order)
     double   rsum[NT / 16][17];      // per row of 16 lanes: autocorrelation sums of one lag group
     uint32_t ored, neq;
 };
@@ -594,10 +594,8 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
     CandStats *cs = reinterpret_cast<CandStats *>(stats + (uint64_t)unit * stats_stride(M));
     double *cs_ac = reinterpret_cast<double *>(stats + (uint64_t)unit * stats_stride(M) + kStatsHeadBytes);
 
-    if (t == 0) {
-        S.ored = 0; S.neq = 0;
-        for (int k = 0; k < 5; ++k) S.e[k] = 0;
-    }
+    if (t == 0) { S.ored = 0; S.neq = 0; }
+    if (t < 80) (&S.e[0][0])[t] = 0;
     // ---- load, wasted bits, constant test
     int32_t v[kRun];
     uint32_t ored = 0, neq = 0;
@@ -699,11 +697,9 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
                 for (int k = 0; k < 5; ++k) e64[k] += e32[k];
             }
         }
+        // five LDS additions per lane (four lanes of a wave share a slot) instead of five 64-bit sums over the row in registers
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const uint64_t rs = row_sum64(e64[k]);
-            if ((lane & 15) == 0 && rs) atomicAdd((unsigned long long *)&S.e[k], (unsigned long long)rs);
-        }
+        for (int k = 0; k < 5; ++k) atomicAdd((unsigned long long *)&S.e[k][t & 15], (unsigned long long)e64[k]);
     }
     // ---- windowed autocorrelation, lags 0..maxo
     uint32_t maxo = o.force_lpc_order ? o.force_lpc_order : o.max_lpc_order;
@@ -748,10 +744,38 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
                     if (l >= 0 && l < LG) acc[l] = __fma_rn(own[j], d, acc[l]);
                 }
             }
+            if constexpr (M <= 12) {
+                // The sum of a lag over the 16 lanes of a row is a balanced tree, neighbours first.  The lanes do not run
+                // it as a butterfly on their own registers (four exchanges and additions for each of the 13 sums, every
+                // lane ending with the same value): the windowed samples are no longer needed, so the sums are laid out
+                // in their place, and one lane per (lag, row, half of the row) adds eight of them in the tree's order;
+                // the two halves of a row sit in neighbouring lanes and meet in one exchange.  Seven lags per pass fit.
+                constexpr int PASS = 7;
+                constexpr uint32_t TS = NT + NT / 8;   // sums of one lag: eight of a lane group, then a pad
+                double *T = reinterpret_cast<double *>(xs);
+                static_assert(PASS * TS * 2 <= enc_lds_words(NT), "a pass of sums fits the sample buffer");
 #pragma unroll
-            for (int l = 0; l < LG; ++l) {
-                const double rs = row_butterfly(acc[l]);
-                if ((lane & 15) == 0) S.rsum[t >> 4][l] = rs;
+                for (int l0 = 0; l0 < LG; l0 += PASS) {
+                    const int np = LG - l0 < PASS ? LG - l0 : PASS;
+                    __syncthreads();   // the windowed samples, or the sums of the pass before, have been read
+#pragma unroll
+                    for (int l = 0; l < PASS; ++l)
+                        if (l < np) T[l * TS + t + (t >> 3)] = acc[l0 + l];
+                    __syncthreads();
+                    if (t < (uint32_t)(NT / 8) * (uint32_t)np) {
+                        const uint32_t g = t % (NT / 8), l = t / (NT / 8);   // g: row * 2 + half
+                        const double *q = T + l * TS + 9 * g;
+                        double sum = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                        sum = sum + dpp_move_f64<FLACGPU_DPP_XOR1>(sum);
+                        if (!(g & 1)) S.rsum[g >> 1][l0 + l] = sum;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int l = 0; l < LG; ++l) {
+                    const double rs = row_butterfly(acc[l]);
+                    if ((lane & 15) == 0) S.rsum[t >> 4][l] = rs;
+                }
             }
             __syncthreads();
             // the butterfly goes on over the four rows of a wave, then the waves are added in ascending order
@@ -768,9 +792,13 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
     } else {
         __syncthreads();
     }
-    if (t == 0) {
+    if (t < 16) {   // (the barriers above are behind every lane's additions)
+        uint64_t e[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) e[k] = row_sum64(S.e[k][t]);
         int fo = 0;
-        for (int k = 1; k <= 4; ++k) if (S.e[k] < S.e[fo]) fo = k;
+        for (int k = 1; k <= 4; ++k) if (e[k] < e[fo]) fo = k;
+        if (t != 0) return;
         if ((uint32_t)fo > bs) fo = (int)bs;
         cs->constant = 0; cs->wasted = (uint32_t)wasted; cs->fo = (uint32_t)fo; cs->lpc_ok = 0;
     }
