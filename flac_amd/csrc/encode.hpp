@@ -259,10 +259,16 @@ __device__ inline void load_block_share(const uint8_t *src, uint32_t bs, int C, 
     const uint32_t t = threadIdx.x;
     if (stereo && B == 2) {
         uint32_t lr[kRun];
+        if (bs == (uint32_t)(NT * kRun)) {   // a whole block: one address per lane and constant offsets, no index to clamp
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src) + t;
 #pragma unroll
-        for (int j = 0; j < kRun; ++j) {
-            const uint32_t i = t + (uint32_t)j * NT;
-            lr[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)(i < bs ? i : bs - 1) * 4);
+            for (int j = 0; j < kRun; ++j) lr[j] = p[j * NT];
+        } else {
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                const uint32_t i = t + (uint32_t)j * NT;
+                lr[j] = *reinterpret_cast<const uint32_t *>(src + (size_t)(i < bs ? i : bs - 1) * 4);
+            }
         }
         // one loop per candidate: the choice is the same for the whole workgroup
         if (cand == 0) {
@@ -347,6 +353,26 @@ __device__ inline uint32_t rice_param(uint64_t sum, uint32_t cnt, uint32_t &est)
 {
     if (cnt == 0) { est = 0; return 0; }
     if (sum == 0) { est = cnt; return 0; }
+    if ((sum >> 31) == 0) {
+        // The common case in 32-bit arithmetic, the four candidates side by side: cnt <= 65536 and k + 1 <= 31, so
+        // cnt * (k + 1) + (sum >> k) stays below 2^32 and every value is the one the 64-bit loop below would find.
+        const uint32_t s32 = (uint32_t)sum;
+        const int k0 = ilog2_32(s32) - ilog2_32(cnt);   // at most 30
+        int lo = k0 - 2, hi = k0 + 1;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi < 0 ? 0 : hi > 30 ? 30 : hi;
+        uint32_t best = 0xFFFFFFFFu, base = cnt * (uint32_t)(lo + 1);
+        int bk = lo;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int k = lo + d;
+            const uint32_t b = base + (s32 >> (k & 31));
+            if (k <= hi && b < best) { best = b; bk = k; }
+            base += cnt;
+        }
+        est = best;
+        return (uint32_t)bk;
+    }
     const int k0 = ilog2_64(sum) - ilog2_32(cnt);
     int lo = k0 - 2, hi = k0 + 1;
     lo = lo < 0 ? 0 : lo > 30 ? 30 : lo;
@@ -412,6 +438,19 @@ __device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c)
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// lo(a) * lo(b) + hi(a) * hi(b) + c on signed 16-bit halves, the sum wrapping in 32 bits: two taps of a predictor whose
+// samples and coefficients fit 16 bits in one instruction.
+__device__ inline int32_t dot2_i16(uint32_t a, uint32_t b, int32_t c)
+{
+    int32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (lo, hi) -> lo's low half in bits 0-15, hi's low half in bits 16-31
+__device__ inline uint32_t pack_halves(int32_t lo, int32_t hi)
+{
+    return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
 
 // Bits [lo, hi) of a lane's 16-sample run, as a mask: the samples i0 + j with first <= i0 + j < end.
 __device__ inline uint32_t run_mask(uint32_t i0, uint32_t first, uint32_t end)
@@ -423,7 +462,8 @@ __device__ inline uint32_t run_mask(uint32_t i0, uint32_t first, uint32_t end)
 
 // LPC residual of the lane's run.  xs / lbase: the block in LDS and the lane's run; cq: the M coefficients in
 // LDS (zero beyond the order).  MODE 0: 24-bit multiply-adds (samples of at most 24 bits, coefficients of at
-// most 15), 1: 32-bit wrapping sums, 2: 64-bit sums.  The taps are taken in passes of at most 16 so that a
+// most 15), 1: 32-bit wrapping sums, 2: 64-bit sums, 3: as 0 for samples of at most 16 bits, two taps per instruction
+// (the same sums modulo 2^32).  The taps are taken in passes of at most 16 so that a
 // pass's coefficients, its window of samples and the 16 running sums fit the registers of a 1024-lane
 // workgroup.  The result is nonzero when some residual of the run may not fit 32 bits (r + 2^31 - 1 has bits
 // above 31 exactly when r is outside [-(2^31 - 1), 2^31 - 1]; MODE 0 has a cheaper test that also reports
@@ -448,6 +488,21 @@ __device__ inline uint32_t lpc_residual(const int32_t *xs, uint32_t lbase, const
         for (int qq = 0; qq < TP; ++qq) c[qq] = cq[cb + base + qq];
 #pragma unroll
         for (int m = 0; m < TP + kRun - 1; ++m) w[m] = xs[lb + lds_rel(m - TP - base)];
+        if constexpr (MODE == 3) {
+            static_assert(TP % 2 == 0, "taps in pairs");
+            uint32_t cp[TP / 2], sp[TP + kRun - 1];   // (c[2p], c[2p + 1]) and (w[m], w[m - 1])
+#pragma unroll
+            for (int pp = 0; pp < TP / 2; ++pp) cp[pp] = pack_halves(c[2 * pp], c[2 * pp + 1]);
+#pragma unroll
+            for (int m = 1; m < TP + kRun - 1; ++m) sp[m] = pack_halves(w[m], w[m - 1]);
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                int32_t sum = (int32_t)acc[j];
+#pragma unroll
+                for (int qq = 0; qq < TP; qq += 2) sum = dot2_i16(cp[qq / 2], sp[TP - 1 - qq + j], sum);
+                acc[j] = (acc_t)(uint32_t)sum;
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < kRun; ++j) {
             if (MODE == 2) {
@@ -466,12 +521,13 @@ __device__ inline uint32_t lpc_residual(const int32_t *xs, uint32_t lbase, const
                 acc[j] = (acc_t)((uint32_t)s0 + (uint32_t)s1);
             }
         }
+        }
     }
     uint32_t high = 0, lb2 = lbase;
     asm volatile("" : "+v"(lb2));
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 3) {
             // samples of at most 24 bits: a prediction inside [-2^30, 2^30) leaves a residual that fits with room
             // to spare; anything else is reported (bit 31 of the sum below) and settled by lpc_residual_bad
             const int32_t pred = (int32_t)(uint32_t)acc[j] >> shift;
@@ -484,7 +540,7 @@ __device__ inline uint32_t lpc_residual(const int32_t *xs, uint32_t lbase, const
             u[j] = fold((int32_t)r);
         }
     }
-    if (MODE == 0) high &= 0x80000000u;
+    if (MODE == 0 || MODE == 3) high &= 0x80000000u;
     return high;
 }
 
@@ -1270,6 +1326,7 @@ __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ p
     if (lpc_ok) {
         uint32_t high;
         if (wide) high = lpc_residual<M, 2>(xs, lbase, S.q, shift, ul);
+        else if (sb <= 16) high = lpc_residual<M, 3>(xs, lbase, S.q, shift, ul);
         else if (sb <= 24) high = lpc_residual<M, 0>(xs, lbase, S.q, shift, ul);
         else high = lpc_residual<M, 1>(xs, lbase, S.q, shift, ul);
         // only residuals that will be coded count
@@ -1593,6 +1650,7 @@ __global__ __launch_bounds__(NT) void k_enc_pack(const uint8_t *__restrict__ pcm
         if (type == 3) {
             const bool wide = (sb + (int)ph.prec + ilog2_32((uint32_t)order)) > 32;
             if (wide) (void)lpc_residual<M, 2>(xs, lbase, s_q, ph.shift, u);
+            else if (sb <= 16) (void)lpc_residual<M, 3>(xs, lbase, s_q, ph.shift, u);
             else if (sb <= 24) (void)lpc_residual<M, 0>(xs, lbase, s_q, ph.shift, u);
             else (void)lpc_residual<M, 1>(xs, lbase, s_q, ph.shift, u);
         } else {
