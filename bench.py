@@ -98,7 +98,7 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
         cpu_enc = {"value": passes * ncpu * nsamples * channels / cpu_s, "unit": "samples/s", "cores": min(threads, ncpu), "kind": "port",
                    "sample": f"{ncpu} files of the workload ({ncpu * pcm_bytes_per_file / 1e6:.0f} MB PCM) encoded {passes} times, "
                              f"oracle/flac_enc_oracle.c, {min(threads, ncpu)} threads, {cpu_s:.2f} s"}
-    kernel_ms = {k: 0.0 for k in ("stats_ms", "design_ms", "choose_ms", "layout_ms", "pack_ms", "crc_ms", "total_ms")}
+    kernel_ms = {k: 0.0 for k in ("pick_ms", "stats_ms", "design_ms", "choose_ms", "layout_ms", "pack_ms", "crc_ms", "total_ms")}
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.encode_steps):
@@ -128,15 +128,33 @@ def encode_leg(args, eng, dev, rank, world, d_pcm, pcm_stride, nfiles, nsamples,
     pcm_total = nfiles * pcm_bytes_per_file
     values = nfiles * nsamples * channels
     alg = pcm_total + flac_total
-    dom = max(("stats_ms", "choose_ms", "pack_ms"), key=lambda k: kernel_ms[k])
-    a_s = kernel_ms[dom] / 1e3
+    # per kernel: its own time (stats_ms covers the pair estimate and the statistics kernel) and its own algorithmic
+    # bytes: every analysis kernel has to read the PCM once; the packer reads it and writes the .flac bytes
+    per_kernel_ms = {"k_enc_pick": kernel_ms["pick_ms"], "k_enc_stats": kernel_ms["stats_ms"] - kernel_ms["pick_ms"],
+                     "k_enc_choose": kernel_ms["choose_ms"], "k_enc_pack": kernel_ms["pack_ms"]}
+    per_kernel_alg = {"k_enc_pick": pcm_total, "k_enc_stats": pcm_total, "k_enc_choose": pcm_total, "k_enc_pack": alg}
+    dom = max(per_kernel_ms, key=lambda k: per_kernel_ms[k])
+    a_s = per_kernel_ms[dom] / 1e3
+    enc_traffic, enc_traffic_src = lookup_encode_traffic(workload_tag(args), nfiles)
+    traffic = traffic_detail = None
+    if enc_traffic:
+        # the CRC-16 pass (k_crc16_spans, shared with the decoder) reads the .flac bytes once more: counted at its algorithmic size
+        whole = sum(v["read"] + v["write"] for v in enc_traffic.values()) + flac_total
+        traffic = enc_traffic[dom]["read"] + enc_traffic[dom]["write"] if dom in enc_traffic else None
+        traffic_detail = {"profile": enc_traffic_src, "per_kernel": enc_traffic, "whole_encode_bytes": whole,
+                          "whole_encode_over_algorithmic": whole / alg,
+                          "note": "the PCM is read by four kernels in turn (pair estimate, statistics, choice, packing)"}
     return {"metric": "encoded PCM samples/sec (per GPU)", "value": values * args.encode_steps / elapsed, "unit": "samples/s",
             "stereo_mode": args.stereo_mode, "steps": args.encode_steps, "ms_per_step": elapsed / args.encode_steps * 1e3, "flac_GB": flac_total / 1e9,
             "ratio": flac_total / pcm_total, "algorithmic_GB_per_s": alg * args.encode_steps / elapsed / 1e9,
             "kernel_ms": kernel_ms, "cpu_baseline": cpu_enc, "round_trip_verified": rt,
-            "roofline": {"bound": "hbm", "kernel": "k_enc_" + dom[:-3], "achieved": alg / a_s / 1e9 if a_s > 0 else 0.0, "peak": 8000.0,
-                         "unit": "GB/s", "frac": alg / a_s / 1e9 / 8000.0 if a_s > 0 else 0.0, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kernel_ms[dom]}}
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel_alg[dom] / a_s / 1e9 if a_s > 0 else 0.0, "peak": 8000.0,
+                         "unit": "GB/s", "frac": per_kernel_alg[dom] / a_s / 1e9 / 8000.0 if a_s > 0 else 0.0,
+                         "traffic": traffic, "traffic_detail": traffic_detail, "limited_by": "valu_issue",
+                         "algorithmic_bytes_per_launch": per_kernel_alg[dom], "avg_launch_ms": per_kernel_ms[dom],
+                         "per_kernel_ms": per_kernel_ms,
+                         "pipeline_frac": alg / (kernel_ms["total_ms"] / 1e3) / 1e9 / 8000.0 if kernel_ms["total_ms"] > 0 else 0.0,
+                         "pipeline_ms": kernel_ms["total_ms"]}}
 
 
 # Named workloads.  cfg3 is the configuration the metric is quoted on (the argparse defaults); cfg4 is the
@@ -239,6 +257,29 @@ def lookup_traffic(tag, kernel, nfiles):
     return None, {"note": f"no committed counter profile of {kernel} on workload {tag}"}
 
 
+def lookup_encode_traffic(tag, nfiles):
+    """Memory-side bytes of every encoder kernel per encode call, from the newest committed request-counter profile of
+    this workload with the encode leg on (profiles/*pmc_enctraffic*.json): 32 x (TCC_EA0_RDREQ_DRAM_32B +
+    TCC_EA0_WRREQ_WRITE_DRAM_32B) per dispatch, scaled by file count.  {kernel family: {"read", "write"}} or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_enctraffic*.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            if pmc.get("workload_tag") != tag:
+                continue
+            scale = nfiles / pmc["files"]
+            out = {}
+            for k, kd in pmc["kernels"].items():
+                if k.startswith("k_enc_"):
+                    out[k.split("<")[0]] = {"read": kd.get("TCC_EA0_RDREQ_DRAM_32B", 0.0) * 32.0 * scale,
+                                            "write": kd.get("TCC_EA0_WRREQ_WRITE_DRAM_32B", 0.0) * 32.0 * scale}
+            if out:
+                return out, os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
+
+
 def lookup_valu(tag, kernel):
     """Vector instructions per sample step of `kernel` (SQ_INSTS_VALU / waves / block size) from the newest committed
     SQ counter profile of this workload (profiles/*pmc_valu*.json), or None."""
@@ -254,6 +295,21 @@ def lookup_valu(tag, kernel):
 
 
 NOMINAL_CLOCK_MHZ = 2400.0   # MI355X peak engine clock
+
+
+def lookup_clock(tag, kernel):
+    """Median clock in MHz the chip held under `kernel` in the newest committed probe run of this workload
+    (profiles/*clock*.json, written by profiles/make_clock_json.py from a library built with the clock probe), or None."""
+    import glob
+    short = "decode" if kernel.startswith("k_decode") else kernel.replace("k_scan_tiles", "scan").replace("k_skim", "skim")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*clock*.json")), reverse=True):
+        try:
+            probe = json.load(open(path))
+            if probe.get("workload_tag") == tag and short in probe["kernels"]:
+                return float(probe["kernels"][short]["clock_MHz_median"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
 
 
 def device_description(torch, dev):
@@ -274,10 +330,17 @@ def valu_issue(tag, kernel, values, seconds, device):
     clock = clock_mhz * 1e6
     peak = device["compute_units"] * 4 * clock / 4.0
     rate = per_step * (values / 64.0) / seconds
-    return {"insts_per_sample_step": per_step, "source": src, "sample_steps_per_launch": values / 64.0,
-            "issue_peak_per_s": peak, "frac": rate / peak, "clock_MHz_nominal": clock_mhz,
-            # the clock at which the launch's instructions alone would fill every issue slot of its duration
-            "clock_MHz_if_all_slots_filled": clock_mhz * rate / peak}
+    out = {"insts_per_sample_step": per_step, "source": src, "sample_steps_per_launch": values / 64.0,
+           "issue_peak_per_s": peak, "frac": rate / peak, "clock_MHz_nominal": clock_mhz,
+           # the clock at which the launch's instructions alone would fill every issue slot of its duration
+           "clock_MHz_if_all_slots_filled": clock_mhz * rate / peak}
+    measured, clock_src = lookup_clock(tag, kernel)
+    if measured:
+        # the clock the chip held under this kernel in the committed probe run: the fraction of the issue slots of
+        # THAT clock is what says whether the kernel has slots to spare (box and run differ by a few percent)
+        out.update({"clock_MHz_measured": measured, "clock_source": clock_src,
+                    "frac_at_measured_clock": out["clock_MHz_if_all_slots_filled"] / measured})
+    return out
 
 
 def host_description():

@@ -171,7 +171,8 @@ class EncodeTiming(ctypes.Structure):
     _fields_ = [("stats_ms", ctypes.c_float), ("design_ms", ctypes.c_float), ("choose_ms", ctypes.c_float),
                 ("layout_ms", ctypes.c_float), ("pack_ms", ctypes.c_float),
                 ("crc_ms", ctypes.c_float), ("md5_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("frames", ctypes.c_uint64), ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64)]
+                ("frames", ctypes.c_uint64), ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64),
+                ("pick_ms", ctypes.c_float), ("reserved", ctypes.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -63,6 +63,7 @@ int launch_analysis(flacgpu_handle *h, uint32_t, size_t lds, hipStream_t st, con
         }
         HIP_TRY(hipGetLastError());
     }
+    if (timing) HIP_TRY(hipEventRecord(h->eev[EE_PICK], st));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_stats<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_choose<M, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // a launch holds fewer than 2^32 work-items, so large batches go in several launches
@@ -284,7 +285,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
         else rc = launch_analysis<32, 1024>(h, grid_a, xs_bytes, st, pcm, ds, n_streams, hints_a, o, win, stats, plans, timing, any_estimated, pick_direct);
         if (rc) return rc;
     } else if (timing) {
-        HIP_TRY(hipEventRecord(h->eev[EE_STATS], st)); HIP_TRY(hipEventRecord(h->eev[EE_DESIGN], st)); HIP_TRY(hipEventRecord(h->eev[EE_CHOOSE], st));
+        HIP_TRY(hipEventRecord(h->eev[EE_PICK], st)); HIP_TRY(hipEventRecord(h->eev[EE_STATS], st)); HIP_TRY(hipEventRecord(h->eev[EE_DESIGN], st)); HIP_TRY(hipEventRecord(h->eev[EE_CHOOSE], st));
     }
     k_enc_layout<<<n_streams, 256, 0, st>>>(ds, o, plans, fr, (uint64_t *)h->e_crc_off.p, (uint32_t *)h->e_crc_len.p, out, md5 ? 1 : 0);
     if (timing) HIP_TRY(hipEventRecord(h->eev[EE_LAYOUT], st));
@@ -323,6 +324,7 @@ int flacgpu_encode_batch_device(flacgpu_handle *h, const void *d_pcm, uint64_t p
     if (timing) {
         auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, h->eev[a], h->eev[b]); return ms; };
         t.stats_ms = el(EE_START, EE_STATS);
+        t.pick_ms = el(EE_START, EE_PICK);
         t.design_ms = el(EE_STATS, EE_DESIGN);
         t.choose_ms = el(EE_DESIGN, EE_CHOOSE);
         t.layout_ms = el(EE_CHOOSE, EE_LAYOUT);
@@ -381,7 +383,7 @@ int flacgpu_encode_batch(flacgpu_handle *h, const uint8_t *const *pcm, const fla
         const int rc = flacgpu_encode_batch_device(h, d_in, in_bytes + 256, d_out, out_bytes + 256, ss.data(), (uint32_t)count, opts,
                                                    results + first, st);
         const flacgpu_encode_timing &t = h->enc_timing;
-        sum.stats_ms += t.stats_ms; sum.design_ms += t.design_ms; sum.choose_ms += t.choose_ms; sum.layout_ms += t.layout_ms;
+        sum.pick_ms += t.pick_ms; sum.stats_ms += t.stats_ms; sum.design_ms += t.design_ms; sum.choose_ms += t.choose_ms; sum.layout_ms += t.layout_ms;
         sum.pack_ms += t.pack_ms; sum.crc_ms += t.crc_ms; sum.md5_ms += t.md5_ms; sum.total_ms += t.total_ms;
         sum.frames += t.frames; sum.in_bytes += t.in_bytes; sum.out_bytes += t.out_bytes;
         return rc;

@@ -419,6 +419,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint8_t *__re
     __shared__ uint16_t s_hits[kHitCap];
     __shared__ uint32_t s_nhits, s_count;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    variant::ClockProbe probe;
+    probe.begin();
 #pragma unroll
     for (int k = 0; k < (int)(kScanTileBytes / 32 / kScanThreads); ++k) s_mask[k * kScanThreads + tid] = 0;   // consecutive lanes, consecutive banks
     if (tid == 0) { s_nhits = 0; s_count = 0; }
@@ -622,6 +624,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const uint8_t *__re
     if (cnt) atomicAdd(&s_count, cnt);
     __syncthreads();
     if (tid == 0) tile_count[blockIdx.x] = s_count;
+    probe.end("scan", 4096);
 }
 
 // Exclusive prefix sum of the tile counts in two levels: within groups of kPrefixGroup tiles (one

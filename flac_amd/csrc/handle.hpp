@@ -21,7 +21,7 @@ struct DevBuf {
 struct HostPipe;   // host_stage.hpp: pinned staging buffers and copy streams of the host-buffer entry points
 
 enum { EV_START, EV_SCAN, EV_COMPACT, EV_CRC, EV_RESOLVE, EV_SKIM, EV_DECODE, EV_RESULTS, EV_COUNT };
-enum { EE_START, EE_STATS, EE_DESIGN, EE_CHOOSE, EE_LAYOUT, EE_PACK, EE_CRC, EE_END, EE_MD5_START, EE_MD5_END, EE_COUNT };
+enum { EE_START, EE_PICK, EE_STATS, EE_DESIGN, EE_CHOOSE, EE_LAYOUT, EE_PACK, EE_CRC, EE_END, EE_MD5_START, EE_MD5_END, EE_COUNT };
 
 }  // namespace flacgpu
 

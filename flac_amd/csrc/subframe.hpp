@@ -380,6 +380,8 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *wave_ring = s_ring + (threadIdx.x >> 6) * (kSlots * 64);
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    variant::ClockProbe probe;
+    probe.begin();
     bool active = item < map.count;
     const uint32_t r = active ? map.candidate(item) : 0u;
     if (active) active = c.status[r] == kFrameOK;
@@ -570,6 +572,7 @@ __global__ __launch_bounds__(256) void k_skim(const uint8_t *__restrict__ in, ui
     }
     if (alive && C) c.subpos[(uint64_t)r * 8 + (C - 1)] = br.pos();
     if (active && rc) c.status[r] = rc;
+    probe.end("skim", 256);
 }
 
 // ------------------------------------------------------------------ decode --
@@ -721,6 +724,8 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
         return;
     }
     if (!p.check_flag && lane == 0) p.class_flags[(NT == 12 ? 0 : 1) + 2 * ARITH] = 1;   // for the timing report only
+    variant::ClockProbe probe;
+    probe.begin();
 
     const uint32_t bs_max = wave_max_u32(active ? bs : 0);
     // a frame's destination, block size (bits 0-19; 0 when the frame is not decoded) and channel assignment
@@ -1579,6 +1584,7 @@ __global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p
         }
         if (status != kFrameOK) atomicMax(&p.c.status[r], status);
     }
+    probe.end("decode", 1024);
 }
 
 // ORs the class flags of one run of streams into a mask (bit = class index) that the timing report carries.

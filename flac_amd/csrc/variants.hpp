@@ -47,6 +47,26 @@ constexpr bool kNoPredictor = true;
 constexpr bool kNoPredictor = false;
 #endif
 
+#ifdef FLACGPU_CLOCK_PROBE      // a few waves of the big kernels print the cycle counter against the constant-rate counter
+constexpr bool kClockProbe = true;   // over their lifetime: the clock the chip holds under that kernel
+#else
+constexpr bool kClockProbe = false;
+#endif
+// Start of a probed region: cycle counter and constant-rate (100 MHz) counter.
+struct ClockProbe {
+    uint64_t c0, w0;
+    __device__ inline void begin() { if constexpr (kClockProbe) { c0 = clock64(); w0 = wall_clock64(); } }
+    __device__ inline void end(const char *what, uint32_t every) const
+    {
+        if constexpr (kClockProbe) {
+            if (threadIdx.x == 0 && blockIdx.x % every == 0) {
+                const uint64_t dc = clock64() - c0, dw = wall_clock64() - w0;
+                printf("clockprobe %s block %u cycles %llu ticks %llu\n", what, blockIdx.x, (unsigned long long)dc, (unsigned long long)dw);
+            }
+        }
+    }
+};
+
 // ---- tuning constants
 #ifdef FLACGPU_RING_LOG2
 constexpr uint32_t kRingLog2 = FLACGPU_RING_LOG2;

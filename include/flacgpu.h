@@ -456,6 +456,8 @@ typedef struct flacgpu_encode_timing {
     uint64_t frames;
     uint64_t in_bytes;   /* PCM bytes encoded                                         */
     uint64_t out_bytes;  /* .flac bytes produced                                      */
+    float pick_ms;       /* the part of stats_ms spent on the stereo pair estimate    */
+    float reserved;
 } flacgpu_encode_timing;
 
 /* Largest possible size of one encoded stream without a seek table: a capacity

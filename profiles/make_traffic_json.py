@@ -20,7 +20,8 @@ for path in sys.argv[4:]:
         if v == 0 and not k.startswith("k_decode"):
             continue
         kernels.setdefault(k, {})[names.get(c, c)] = v
-kernels = {k: v for k, v in kernels.items() if v.get("WRITE_SIZE_KiB", 0) > 1 or v.get("FETCH_SIZE_KiB", 0) > 1}
+kernels = {k: v for k, v in kernels.items() if v.get("WRITE_SIZE_KiB", 0) > 1 or v.get("FETCH_SIZE_KiB", 0) > 1
+           or v.get("TCC_EA0_RDREQ_DRAM_32B", 0) > 32 or v.get("TCC_EA0_WRREQ_WRITE_DRAM_32B", 0) > 32}
 import subprocess
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
 json.dump({"workload_tag": tag, "files": files, "commit": commit,
