@@ -29,6 +29,29 @@ def test_presets_name_the_baseline_configurations():
     assert c["files"] * c["seconds"] * c["rate"] * c["channels"] * 3 >= 8e9      # at least 8 GB of PCM per GPU
 
 
+def test_committed_profiles_feed_the_roofline_fields():
+    """The bench line's traffic, instruction and clock figures come from committed counter profiles keyed by the
+    workload: the default workload must find all of them, and an unknown workload none (null fields, not stale ones)."""
+    tag = "44100Hz_16bit_2ch_bs4096_lpc12_force0_po6_fpo-1_60s"
+    kernel = "k_decode<12, 3, 1>"
+    traffic, detail = bench.lookup_traffic(tag, kernel, 10000)
+    assert traffic and detail["read_side_used"].startswith("32 x") and detail["write_bytes"] > 1.05e11
+    assert 1.0 < traffic / (detail["write_bytes"] + 6.1e10) < 1.5          # reads: between once and twice the input
+    per_step, src = bench.lookup_valu(tag, kernel)
+    assert 25 < per_step < 40 and src.startswith("profiles/")
+    clock, csrc = bench.lookup_clock(tag, kernel)
+    assert 1500 < clock < 2400 and csrc.startswith("profiles/")
+    v = bench.valu_issue(tag, kernel, 5.29e10, 0.0521, {"compute_units": 256, "clock_MHz": None})
+    assert 0.7 < v["frac"] < 0.9 and 0.8 < v["frac_at_measured_clock"] < 1.1
+    enc, esrc = bench.lookup_encode_traffic(tag, 10000)
+    assert set(enc) >= {"k_enc_pick", "k_enc_stats", "k_enc_choose", "k_enc_pack"} and esrc.startswith("profiles/")
+    assert all(0.95 < enc[k]["read"] / 1.0584e11 < 1.1 for k in ("k_enc_pick", "k_enc_stats", "k_enc_choose", "k_enc_pack"))
+    assert bench.lookup_traffic("no such workload", kernel, 10)[0] is None
+    assert bench.lookup_valu("no such workload", kernel) == (None, None)
+    assert bench.lookup_clock("no such workload", kernel) == (None, None)
+    assert bench.lookup_encode_traffic("no such workload", 10) == (None, None)
+
+
 def test_more_gpus_than_the_node_has_is_refused():
     import torch
     have = torch.cuda.device_count()
