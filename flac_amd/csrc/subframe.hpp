@@ -39,13 +39,13 @@ namespace flacgpu {
 constexpr uint32_t kRingLog2 = variant::kRingLog2;
 constexpr uint32_t kRingWords = 1u << kRingLog2;   // ring capacity per lane, in 32-bit words
 constexpr uint32_t kRingSlots = kRingWords + 1;    // the last slot repeats slot 0, so that words w and w + 1 are always one two-word read
-constexpr uint32_t kUnitWords = 8;    // refill granule: 32 bytes
+constexpr uint32_t kUnitWords = variant::kUnitWords;   // refill granule: 32 bytes
 constexpr uint32_t kRoundSteps = variant::kRoundSteps;   // decode steps (of at most 32 bits) between refill rounds
 constexpr uint32_t kRingBytesPerWave = kRingSlots * 64 * 4;
 constexpr uint32_t kNoFill = 0xFFFFFFFFu;
 // A lane fetches its next unit when it has this many unread words or fewer.  The unit lands one round later
 // on the ring's oldest words, which the reader must have passed by then: at most kRingWords - kUnitWords.
-constexpr uint32_t kFetchBelow = kRingWords >= 32 ? 17 : kRingWords - kUnitWords;
+constexpr uint32_t kFetchBelow = kRingWords >= 32 ? kRingWords - kUnitWords - 7 : kRingWords - kUnitWords;
 constexpr uint32_t kSkimPairK = variant::kSkimPairK;
 // Compile-time loops: the body gets its index as a std::integral_constant (the unrolled loops index register arrays).
 template <int N, int I = 0, class F>
@@ -201,9 +201,14 @@ struct BitReader {
 // What a lane holds between two refill rounds: the 32 bytes it loaded for its ring and the ring
 // position they belong to.
 struct RingFetch {
-    uint4 v[2];
+    uint4 v[kUnitWords / 4];
     uint32_t at;   // `fill` when the load was issued, or kNoFill
-    __device__ inline void clear() { at = kNoFill; v[0] = v[1] = uint4{0u, 0u, 0u, 0u}; }
+    __device__ inline void clear()
+    {
+        at = kNoFill;
+#pragma unroll
+        for (uint32_t i = 0; i < kUnitWords / 4; ++i) v[i] = uint4{0u, 0u, 0u, 0u};
+    }
 };
 
 // One refill round; all 64 lanes call it together, every kRoundSteps decode steps.
@@ -230,10 +235,13 @@ __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active)
         dst[1 * 64] = __builtin_bswap32(rf.v[0].y);
         dst[2 * 64] = __builtin_bswap32(rf.v[0].z);
         dst[3 * 64] = __builtin_bswap32(rf.v[0].w);
-        dst[4 * 64] = __builtin_bswap32(rf.v[1].x);
-        dst[5 * 64] = __builtin_bswap32(rf.v[1].y);
-        dst[6 * 64] = __builtin_bswap32(rf.v[1].z);
-        dst[7 * 64] = __builtin_bswap32(rf.v[1].w);
+#pragma unroll
+        for (uint32_t i = 1; i < kUnitWords / 4; ++i) {
+            dst[(4 * i + 0) * 64] = __builtin_bswap32(rf.v[i].x);
+            dst[(4 * i + 1) * 64] = __builtin_bswap32(rf.v[i].y);
+            dst[(4 * i + 2) * 64] = __builtin_bswap32(rf.v[i].z);
+            dst[(4 * i + 3) * 64] = __builtin_bswap32(rf.v[i].w);
+        }
         if (slot == 0) {
             br.ring[kRingWords * 64] = w0;
             if (MIRROR2) br.ring[(kRingWords + 1) * 64] = __builtin_bswap32(rf.v[0].y);
@@ -248,8 +256,8 @@ __device__ inline void ring_round(BitReader &br, RingFetch &rf, bool active)
     // the loads are unconditional (a lane with nothing to fetch reads the spare bytes): a branch
     // around them would make the compiler copy the result, and so wait for it, right here
     const uint4 *src = want ? reinterpret_cast<const uint4 *>(br.gbase + br.fill) : br.spare;
-    rf.v[0] = src[0];
-    rf.v[1] = src[1];
+#pragma unroll
+    for (uint32_t i = 0; i < kUnitWords / 4; ++i) rf.v[i] = src[want ? i : (i & 1)];   // (the spare bytes are 32)
 }
 
 // Unary-coded count: zeros up to and including the terminating one are consumed.

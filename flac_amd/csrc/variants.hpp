@@ -73,6 +73,11 @@ constexpr uint32_t kRingLog2 = FLACGPU_RING_LOG2;
 #else
 constexpr uint32_t kRingLog2 = 5;        // ring capacity per lane: 32 words
 #endif
+#ifdef FLACGPU_UNIT_WORDS
+constexpr uint32_t kUnitWords = FLACGPU_UNIT_WORDS;
+#else
+constexpr uint32_t kUnitWords = 8;       // words a lane fetches for its ring at a time: one 32-byte sector
+#endif
 #ifdef FLACGPU_ROUND_STEPS
 constexpr uint32_t kRoundSteps = FLACGPU_ROUND_STEPS;
 #else
