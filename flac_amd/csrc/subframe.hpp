@@ -649,7 +649,7 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t C)
 // boundary inside the group, escape-coded or verbatim data, the tail of a block)
 // runs the generic rolled body with a shift-register history.
 template <int NT, int ARITH, int LAYOUT>
-__global__ __launch_bounds__(256, NT == 12 ? 3 : 2) void k_decode(DecodeParams p)   // LDS admits three blocks per CU; the 12-tap classes keep their registers within that
+__global__ __launch_bounds__(256, NT == 12 ? 3 : variant::kWaves32) void k_decode(DecodeParams p)   // LDS admits three blocks per CU; the 12-tap classes keep their registers within that
 {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int U = class_unroll(NT);

@@ -78,6 +78,11 @@ constexpr uint32_t kUnitWords = FLACGPU_UNIT_WORDS;
 #else
 constexpr uint32_t kUnitWords = 8;       // words a lane fetches for its ring at a time: one 32-byte sector
 #endif
+#ifdef FLACGPU_WAVES32
+constexpr int kWaves32 = FLACGPU_WAVES32;
+#else
+constexpr int kWaves32 = 2;              // workgroups per CU the 32-tap decode classes are compiled for (registers: 252 at 2)
+#endif
 #ifdef FLACGPU_ROUND_STEPS
 constexpr uint32_t kRoundSteps = FLACGPU_ROUND_STEPS;
 #else
