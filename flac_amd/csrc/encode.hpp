@@ -873,8 +873,6 @@ __global__ __launch_bounds__(NT) void k_enc_stats(const uint8_t *__restrict__ pc
 template <int NT>
 struct PickShared {
     float  rs[NT / 16][15];          // per row of 16 lanes: left, right, side x 5 lags
-    float  ac[15];
-    double est[4];
 };
 
 // Left and right samples of the lane's share of a stereo block (see load_block_share).
@@ -919,7 +917,8 @@ struct __attribute__((packed, aligned(4))) EncDwords4 { uint32_t a, b, c, d; };
 template <int NT, bool DIRECT>
 __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm, const EncStreamDev *__restrict__ streams,
                                                  uint32_t n_streams, const uint32_t *__restrict__ hints, EncOptsDev o,
-                                                 const float *__restrict__ windows, uint32_t pair_base, uint32_t pair_end)
+                                                 const float *__restrict__ windows, float *__restrict__ sums,
+                                                 uint32_t pair_base, uint32_t pair_end)
 {
     extern __shared__ __align__(16) int32_t xs[];   // !DIRECT: two blocks of enc_lds_words(NT): w*l and w*r, see lds_pos
     float *xl = reinterpret_cast<float *>(xs), *xr = xl + enc_lds_words(NT);
@@ -1007,10 +1006,31 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
     if (t < 15) {
         float total = S.rs[0][t];
         for (int row = 1; row < NT / 16; ++row) total = total + S.rs[row][t];
-        S.ac[t] = total;
+        sums[(uint64_t)(st.frame_begin + f) * 16 + t] = total;   // k_enc_pick_mode takes it from here
     }
-    __syncthreads();
-    if (t < 4) {
+}
+
+// Channel pair of a frame from the 15 sums k_enc_pick left for it (left, right, side x lags 0..4), one LANE per frame:
+// four short Levinson-Durbin recursions and a comparison, serial arithmetic that kept one wave of every k_enc_pick
+// workgroup busy while the other three waited.
+__global__ __launch_bounds__(64) void k_enc_pick_mode(const EncStreamDev *__restrict__ streams, uint32_t n_streams,
+                                                      const uint32_t *__restrict__ hints, EncOptsDev o,
+                                                      const float *__restrict__ sums, uint32_t n_pairs)
+{
+    const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= n_pairs) return;
+    const uint32_t unit = 2 * pi;
+    const EncStreamDev &st = streams[find_enc_stream(streams, n_streams, hints, unit, 0)];
+    if (st.pair != kPairEstimated) return;
+    const uint32_t f = (unit - st.unit_begin) >> 1;
+    if (f >= st.n_frames) return;
+    const uint32_t bs = f + 1 == st.n_frames ? st.tail_bs : o.blocksize;
+    float sac[15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) sac[q] = sums[(uint64_t)(st.frame_begin + f) * 16 + q];
+    double ests[4];
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t) {
         // estimated size of the subframe of signal t: the cheapest of orders 1..4 by the rule of k_enc_design
         const int cbps = (int)st.bps + (t == 3 ? 1 : 0);
         int prec0 = o.qlp_precision ? (int)o.qlp_precision : default_precision((int)st.bps, bs);
@@ -1018,7 +1038,7 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
         double ac[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            const double al = (double)S.ac[q], ar = (double)S.ac[5 + q], as = (double)S.ac[10 + q];
+            const double al = (double)sac[q], ar = (double)sac[5 + q], as = (double)sac[10 + q];
             ac[q] = t == 0 ? al : t == 1 ? ar : t == 3 ? as : (2.0 * (al + ar) - as) * 0.25;
         }
         double est = 0.0;
@@ -1053,15 +1073,12 @@ __global__ __launch_bounds__(NT) void k_enc_pick(const uint8_t *__restrict__ pcm
                 }
             }
         }
-        S.est[t] = est;
+        ests[t] = est;
     }
-    __syncthreads();
-    if (t == 0) {
-        const double b[4] = {S.est[0] + S.est[1], S.est[0] + S.est[3], S.est[3] + S.est[1], S.est[2] + S.est[3]};
-        int mode = 0;
-        for (int k = 1; k < 4; ++k) if (b[k] < b[mode]) mode = k;
-        o.modes[st.frame_begin + f] = (uint8_t)mode;
-    }
+    const double b[4] = {ests[0] + ests[1], ests[0] + ests[3], ests[3] + ests[1], ests[2] + ests[3]};
+    int mode = 0;
+    for (int k = 1; k < 4; ++k) if (b[k] < b[mode]) mode = k;
+    o.modes[st.frame_begin + f] = (uint8_t)mode;
 }
 
 // Levinson-Durbin, order choice and coefficient quantisation: one lane per candidate channel, every array

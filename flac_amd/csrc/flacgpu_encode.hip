@@ -53,14 +53,18 @@ int launch_analysis(flacgpu_handle *h, uint32_t, size_t lds, hipStream_t st, con
                     bool timing, bool pick, bool pick_direct)
 {
     if (pick) {
-        // channel pair of every frame of the streams that asked for the estimate, before any candidate is analysed
+        // channel pair of every frame of the streams that asked for the estimate, before any candidate is analysed.
+        // The estimate's sums of a frame (16 floats) wait for k_enc_pick_mode in the statistics buffer, which
+        // k_enc_stats only fills afterwards and which holds at least 200 bytes for every frame.
+        float *sums = reinterpret_cast<float *>(stats);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_enc_pick<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
         const uint32_t pairs = o.total_units / 2, pchunk = (0xF0000000u / NT) & ~7u;
         for (uint32_t b = 0; b < pairs; b += pchunk) {
             const uint32_t e = pairs - b < pchunk ? pairs : b + pchunk;
-            if (pick_direct) k_enc_pick<NT, true><<<(e - b + 7) / 8 * 8, NT, 0, st>>>(pcm, s, n, hints, o, win, b, e);   // 16-bit samples only: no LDS staging
-            else k_enc_pick<NT, false><<<(e - b + 7) / 8 * 8, NT, 2 * lds, st>>>(pcm, s, n, hints, o, win, b, e);
+            if (pick_direct) k_enc_pick<NT, true><<<(e - b + 7) / 8 * 8, NT, 0, st>>>(pcm, s, n, hints, o, win, sums, b, e);   // 16-bit samples only: no LDS staging
+            else k_enc_pick<NT, false><<<(e - b + 7) / 8 * 8, NT, 2 * lds, st>>>(pcm, s, n, hints, o, win, sums, b, e);
         }
+        k_enc_pick_mode<<<(pairs + 63) / 64, 64, 0, st>>>(s, n, hints, o, sums, pairs);
         HIP_TRY(hipGetLastError());
     }
     if (timing) HIP_TRY(hipEventRecord(h->eev[EE_PICK], st));
