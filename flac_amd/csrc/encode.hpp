@@ -1403,10 +1403,11 @@ __global__ __launch_bounds__(NT) void k_enc_choose(const uint8_t *__restrict__ p
 
 __device__ inline uint32_t crc8_byte(uint32_t c, uint32_t byte)
 {
-    c ^= byte;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) c = (c & 0x80) ? ((c << 1) ^ 0x07) & 0xFF : (c << 1) & 0xFF;
-    return c;
+    // (c ^ byte) * x^8 modulo x^8 + x^2 + x + 1, by the relation x^8 = x^2 + x + 1 applied twice
+    const uint32_t t = c ^ byte;
+    const uint32_t h = t ^ (t << 1) ^ (t << 2);
+    const uint32_t hi = h >> 8;
+    return (h & 0xFFu) ^ hi ^ (hi << 1) ^ (hi << 2);
 }
 
 // Header of a fixed-blocksize frame.  Returns its length in bytes (CRC-8 included).
